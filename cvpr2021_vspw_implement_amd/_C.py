@@ -1,0 +1,110 @@
+"""ctypes binding of libvspw_hip.so (the C ABI declared in include/vspw_hip.h).
+
+The header is the single source of truth: its declarations are parsed here to build the ctypes signatures, and the
+CPU test-suite uses the same parser to check that the built library exports every declared symbol.
+There is NO fallback: if the library is missing, or a tensor is not on the GPU, the product path raises.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "vspw_hip.h")
+LIB_PATH = os.path.join(_HERE, "lib", "libvspw_hip.so")
+
+
+class ConvDesc(ctypes.Structure):
+    """struct vspw_conv_desc (include/vspw_hip.h)."""
+
+    _fields_ = [(n, ctypes.c_int) for n in ("n", "h", "w", "c", "oh", "ow", "k", "kh", "kw", "stride", "pad", "dil")]
+
+
+_CTYPES = {
+    "int": ctypes.c_int,
+    "long long": ctypes.c_longlong,
+    "float": ctypes.c_float,
+    "double": ctypes.c_double,
+    "size_t": ctypes.c_size_t,
+}
+
+
+def _arg_ctype(decl: str):
+    decl = decl.strip()
+    if "*" in decl:
+        if "vspw_conv_desc" in decl:
+            return ctypes.POINTER(ConvDesc)
+        return ctypes.c_void_p
+    # strip the parameter name
+    toks = decl.replace("const ", "").split()
+    ty = " ".join(toks[:-1]) if len(toks) > 1 else toks[0]
+    return _CTYPES[ty]
+
+
+def parse_header(path: str = HEADER):
+    """Return {name: (restype, [argtypes])} for every function declared in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    src = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(int|size_t)\s+(vspw_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        args = " ".join(args.split())
+        if args in ("", "void"):
+            argtypes = []
+        else:
+            argtypes = [_arg_ctype(a) for a in args.split(",")]
+        out[name] = (_CTYPES[ret], argtypes)
+    return out
+
+
+_lib = None
+
+
+def load(check_symbols: bool = False):
+    """Load the shared library (once). Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is not None and not check_symbols:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libvspw_hip.so is missing (%s). Build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback for the hot path." % LIB_PATH
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    decls = parse_header()
+    missing = []
+    for name, (ret, argtypes) in decls.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = ret
+        fn.argtypes = argtypes
+    if missing:
+        raise RuntimeError("libvspw_hip.so does not export: " + ", ".join(missing))
+    if lib.vspw_abi_version() != 1:
+        raise RuntimeError("libvspw_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "VSPW_EINVAL (bad argument / geometry / workspace)", -2: "VSPW_ELAUNCH (HIP launch failure)"}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, _ERR.get(rc, str(rc))))
+
+
+def call(name: str, *args):
+    """Call an int-returning entry point and raise on a non-zero status."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        check(rc, name)
+
+
+def query(name: str, *args):
+    """Call a size_t-returning *_workspace()/partials() entry point."""
+    return getattr(load(), name)(*args)

@@ -1,0 +1,386 @@
+// BatchNorm (training + eval) fused with ReLU / residual add / Dropout2d mask, NHWC fp32, gfx950.
+//
+// Replaces SynchronizedBatchNorm2d.forward (models/sync_batchnorm/batchnorm.py:68-98, i.e. F.batch_norm with
+// momentum 0.1 / eps 1e-5 on a single device, or the sum/ssum exchange of :110-150 across devices) plus the
+// nn.ReLU / `out += residual` / nn.Dropout2d that follow it in models/resnet.py:40-51,75-90,
+// models/clip_psp.py:36-39,75-78, models/clip_ocr.py:44-45,59-61, and the autograd backward of all of them.
+//
+// All kernels are HBM-bound streaming passes over a [rows][C] matrix (rows = N*H*W pixels):
+//   stats      : 1 read                       -> per-channel sum, sum of squares (fp64 accumulation)
+//   apply      : 1-2 reads, 1 write           -> z = relu(x*scale+shift (+res)) (*mask)
+//   bwd_reduce : 3 reads                      -> sum g, sum g*xhat
+//   bwd_apply  : 3 reads, 1-2 writes          -> dx (, dres)
+// The cross-rank SyncBN exchange happens between stats and finalize (host side, RCCL all-reduce of `sums`).
+#include "common.h"
+
+#define RED_TX 32  // threads across channels (each 4 channels)
+#define RED_TY 8   // row lanes
+
+// partial[split][2][c] (fp64)
+__global__ __launch_bounds__(RED_TX * RED_TY) void bn_stats_kernel(const float* __restrict__ x, long long rows, int c,
+                                                                  double* __restrict__ part) {
+    __shared__ double red[2][RED_TY][RED_TX * 4];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int c0 = (blockIdx.x * RED_TX + tx) * 4;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const bool vec = (c % 4 == 0);
+    if (c0 < c) {
+        for (long long r = (long long)blockIdx.y * RED_TY + ty; r < rows; r += (long long)gridDim.y * RED_TY) {
+            const float* px = x + (size_t)r * c + c0;
+            if (vec) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(px);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    double d = (double)v[e];
+                    s[e] += d;
+                    q[e] += d * d;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + e < c) {
+                        double d = (double)px[e];
+                        s[e] += d;
+                        q[e] += d * d;
+                    }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][ty][tx * 4 + e] = s[e];
+        red[1][ty][tx * 4 + e] = q[e];
+    }
+    __syncthreads();
+    const int t = ty * RED_TX + tx;  // 0..255
+    if (t < RED_TX * 4) {
+        const int ch = blockIdx.x * RED_TX * 4 + t;
+        if (ch < c) {
+            double a = 0, b = 0;
+#pragma unroll
+            for (int j = 0; j < RED_TY; ++j) {
+                a += red[0][j][t];
+                b += red[1][j][t];
+            }
+            double* out = part + (size_t)blockIdx.y * 2 * c;
+            out[ch] = a;
+            out[c + ch] = b;
+        }
+    }
+}
+
+__global__ void reduce_partials_f64_kernel(const double* __restrict__ part, double* __restrict__ sums, int splits,
+                                           int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = 0;
+    for (int z = 0; z < splits; ++z) a += part[(size_t)z * n + i];
+    sums[i] = a;
+}
+
+__global__ void reduce_partials_f32_kernel(const float* __restrict__ part, double* __restrict__ sums, int tiles,
+                                           int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a = 0;
+    for (int z = 0; z < tiles; ++z) a += (double)part[(size_t)z * n + i];
+    sums[i] = a;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean,
+                                   float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
+                                   float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
+                                   int c) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    double m = sums[i] / count;
+    double var = sums[c + i] / count - m * m;
+    if (var < 0) var = 0;
+    float mf = (float)m;
+    float is = (float)(1.0 / sqrt(var + (double)eps));
+    float g = gamma ? gamma[i] : 1.f;
+    float b = beta ? beta[i] : 0.f;
+    mean[i] = mf;
+    invstd[i] = is;
+    float sc = g * is;
+    scale[i] = sc;
+    shift[i] = b - mf * sc;
+    if (rmean) rmean[i] = (1.f - momentum) * rmean[i] + momentum * mf;
+    if (rvar) {
+        double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rvar[i] = (1.f - momentum) * rvar[i] + momentum * (float)unb;
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                      float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale,
+                                      float* __restrict__ shift, int c) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    float mf = rmean[i];
+    float is = 1.f / sqrtf(rvar[i] + eps);
+    float g = gamma ? gamma[i] : 1.f;
+    float b = beta ? beta[i] : 0.f;
+    mean[i] = mf;
+    invstd[i] = is;
+    float sc = g * is;
+    scale[i] = sc;
+    shift[i] = b - mf * sc;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const float* __restrict__ res,
+                                                       const float* __restrict__ mask, float* __restrict__ z,
+                                                       long long rows, int c, long long rpi, int relu) {
+    const int W = VEC ? 4 : 1;
+    const long long cw = c / W;
+    const long long total = rows * cw;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const long long r = i / cw;
+        const int ch = (int)(i - r * cw) * W;
+        const size_t off = (size_t)r * c + ch;
+        if (VEC) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(x + off);
+            f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ch);
+            f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ch);
+            f32x4 o = v * sc + sh;
+            if (res) o += *reinterpret_cast<const f32x4*>(res + off);
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+            }
+            if (mask) o *= *reinterpret_cast<const f32x4*>(mask + (size_t)(r / rpi) * c + ch);
+            *reinterpret_cast<f32x4*>(z + off) = o;
+        } else {
+            float o = x[off] * scale[ch] + shift[ch];
+            if (res) o += res[off];
+            if (relu) o = o > 0.f ? o : 0.f;
+            if (mask) o *= mask[(size_t)(r / rpi) * c + ch];
+            z[off] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(RED_TX * RED_TY) void bn_bwd_reduce_kernel(
+    const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ mask, long long rows,
+    int c, long long rpi, int relu, double* __restrict__ part) {
+    __shared__ double red[2][RED_TY][RED_TX * 4];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int c0 = (blockIdx.x * RED_TX + tx) * 4;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (c0 < c) {
+        float mu[4], is[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mu[e] = (c0 + e < c) ? mean[c0 + e] : 0.f;
+            is[e] = (c0 + e < c) ? invstd[c0 + e] : 0.f;
+        }
+        for (long long r = (long long)blockIdx.y * RED_TY + ty; r < rows; r += (long long)gridDim.y * RED_TY) {
+            const size_t off = (size_t)r * c + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (c0 + e < c) {
+                    float g = dz[off + e];
+                    if (mask) g *= mask[(size_t)(r / rpi) * c + c0 + e];
+                    if (relu && !(z[off + e] > 0.f)) g = 0.f;
+                    float xh = (x[off + e] - mu[e]) * is[e];
+                    s[e] += (double)g;
+                    q[e] += (double)g * (double)xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][ty][tx * 4 + e] = s[e];
+        red[1][ty][tx * 4 + e] = q[e];
+    }
+    __syncthreads();
+    const int t = ty * RED_TX + tx;
+    if (t < RED_TX * 4) {
+        const int ch = blockIdx.x * RED_TX * 4 + t;
+        if (ch < c) {
+            double a = 0, b = 0;
+#pragma unroll
+            for (int j = 0; j < RED_TY; ++j) {
+                a += red[0][j][t];
+                b += red[1][j][t];
+            }
+            double* out = part + (size_t)blockIdx.y * 2 * c;
+            out[ch] = a;
+            out[c + ch] = b;
+        }
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const float* __restrict__ dz, const float* __restrict__ z, const float* __restrict__ x,
+    const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+    const double* __restrict__ sums, double inv_count, const float* __restrict__ mask, long long rows, int c,
+    long long rpi, int relu, int training, float* __restrict__ dx, float* __restrict__ dres) {
+    const int W = VEC ? 4 : 1;
+    const long long cw = c / W;
+    const long long total = rows * cw;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const long long r = i / cw;
+        const int ch = (int)(i - r * cw) * W;
+        const size_t off = (size_t)r * c + ch;
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+            float g = dz[off + e];
+            if (mask) g *= mask[(size_t)(r / rpi) * c + ch + e];
+            if (relu && !(z[off + e] > 0.f)) g = 0.f;
+            if (dres) dres[off + e] = g;
+            if (dx) {
+                float is = invstd[ch + e];
+                float gm = gamma ? gamma[ch + e] : 1.f;
+                float o;
+                if (training) {
+                    float xh = (x[off + e] - mean[ch + e]) * is;
+                    float mg = (float)(sums[ch + e] * inv_count);
+                    float mgx = (float)(sums[c + ch + e] * inv_count);
+                    o = gm * is * (g - mg - xh * mgx);
+                } else {
+                    o = gm * is * g;
+                }
+                dx[off + e] = o;
+            }
+        }
+    }
+}
+
+__global__ void bn_param_grads_kernel(const double* __restrict__ sums, float* __restrict__ dgamma,
+                                      float* __restrict__ dbeta, int c) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    if (dbeta) dbeta[i] = (float)sums[i];
+    if (dgamma) dgamma[i] = (float)sums[c + i];
+}
+
+static void reduce_plan(long long rows, int c, int& gx, int& gy) {
+    gx = vspw_cdiv(c, RED_TX * 4);
+    long long want = (2048 + gx - 1) / gx;
+    long long maxy = (rows + RED_TY - 1) / RED_TY;
+    if (want > maxy) want = maxy;
+    if (want < 1) want = 1;
+    gy = (int)want;
+}
+
+extern "C" size_t vspw_bn_stats_workspace(long long rows, int c) {
+    if (rows <= 0 || c <= 0) return 0;
+    int gx, gy;
+    reduce_plan(rows, c, gx, gy);
+    return (size_t)gy * 2 * c * sizeof(double);
+}
+extern "C" size_t vspw_bn_bwd_workspace(long long rows, int c) { return vspw_bn_stats_workspace(rows, c); }
+
+extern "C" int vspw_bn_stats(const float* x, long long rows, int c, double* sums, void* ws, size_t ws_bytes,
+                             void* stream) {
+    if (!x || !sums || rows <= 0 || c <= 0) return VSPW_EINVAL;
+    int gx, gy;
+    reduce_plan(rows, c, gx, gy);
+    if (!ws || ws_bytes < (size_t)gy * 2 * c * sizeof(double)) return VSPW_EINVAL;
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(gx, gy), dim3(RED_TX, RED_TY), 0, vspw_stream(stream), x, rows, c, part);
+    hipLaunchKernelGGL(reduce_partials_f64_kernel, dim3(vspw_cdiv(2 * c, 256)), dim3(256), 0, vspw_stream(stream),
+                       part, sums, gy, 2 * c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_bn_reduce_partials_f32(const float* part, int tiles, int c, double* sums, void* stream) {
+    if (!part || !sums || tiles <= 0 || c <= 0) return VSPW_EINVAL;
+    hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3(vspw_cdiv(2 * c, 256)), dim3(256), 0, vspw_stream(stream),
+                       part, sums, tiles, 2 * c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                float* invstd, float* scale, float* shift, int c, void* stream) {
+    if (!sums || !mean || !invstd || !scale || !shift || c <= 0 || !(count > 0)) return VSPW_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(vspw_cdiv(c, 256)), dim3(256), 0, vspw_stream(stream), sums, count,
+                       gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, float* mean, float* invstd, float* scale,
+                                   float* shift, int c, void* stream) {
+    if (!running_mean || !running_var || !mean || !invstd || !scale || !shift || c <= 0) return VSPW_EINVAL;
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3(vspw_cdiv(c, 256)), dim3(256), 0, vspw_stream(stream), gamma, beta,
+                       running_mean, running_var, eps, mean, invstd, scale, shift, c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_bn_apply(const float* x, const float* scale, const float* shift, const float* residual,
+                             const float* chan_mask, float* z, long long rows, int c, long long rows_per_image,
+                             int relu, void* stream) {
+    if (!x || !scale || !shift || !z || rows <= 0 || c <= 0) return VSPW_EINVAL;
+    if (chan_mask && rows_per_image <= 0) return VSPW_EINVAL;
+    if (rows_per_image <= 0) rows_per_image = rows;
+    if (c % 4 == 0) {
+        long long total = rows * (c / 4);
+        hipLaunchKernelGGL(bn_apply_kernel<true>, dim3(vspw_stream_grid(total, 256)), dim3(256), 0,
+                           vspw_stream(stream), x, scale, shift, residual, chan_mask, z, rows, c, rows_per_image, relu);
+    } else {
+        long long total = rows * c;
+        hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(vspw_stream_grid(total, 256)), dim3(256), 0,
+                           vspw_stream(stream), x, scale, shift, residual, chan_mask, z, rows, c, rows_per_image, relu);
+    }
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_bn_bwd_reduce(const float* dz, const float* z, const float* x, const float* mean,
+                                  const float* invstd, const float* chan_mask, long long rows, int c,
+                                  long long rows_per_image, int relu, double* sums, void* ws, size_t ws_bytes,
+                                  void* stream) {
+    if (!dz || !x || !mean || !invstd || !sums || rows <= 0 || c <= 0) return VSPW_EINVAL;
+    if (relu && !z) return VSPW_EINVAL;
+    if (chan_mask && rows_per_image <= 0) return VSPW_EINVAL;
+    if (rows_per_image <= 0) rows_per_image = rows;
+    int gx, gy;
+    reduce_plan(rows, c, gx, gy);
+    if (!ws || ws_bytes < (size_t)gy * 2 * c * sizeof(double)) return VSPW_EINVAL;
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(gx, gy), dim3(RED_TX, RED_TY), 0, vspw_stream(stream), dz, z, x, mean,
+                       invstd, chan_mask, rows, c, rows_per_image, relu, part);
+    hipLaunchKernelGGL(reduce_partials_f64_kernel, dim3(vspw_cdiv(2 * c, 256)), dim3(256), 0, vspw_stream(stream),
+                       part, sums, gy, 2 * c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_bn_bwd_apply(const float* dz, const float* z, const float* x, const float* mean,
+                                 const float* invstd, const float* gamma, const double* sums, double count,
+                                 const float* chan_mask, long long rows, int c, long long rows_per_image, int relu,
+                                 int training, float* dx, float* dres, float* dgamma, float* dbeta, void* stream) {
+    if (!dz || !x || !mean || !invstd || !sums || rows <= 0 || c <= 0 || !(count > 0)) return VSPW_EINVAL;
+    if (relu && !z) return VSPW_EINVAL;
+    if (chan_mask && rows_per_image <= 0) return VSPW_EINVAL;
+    if (rows_per_image <= 0) rows_per_image = rows;
+    if (dx || dres) {
+        if (c % 4 == 0) {
+            long long total = rows * (c / 4);
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(vspw_stream_grid(total, 256)), dim3(256), 0,
+                               vspw_stream(stream), dz, z, x, mean, invstd, gamma, sums, 1.0 / count, chan_mask, rows,
+                               c, rows_per_image, relu, training, dx, dres);
+        } else {
+            long long total = rows * c;
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(vspw_stream_grid(total, 256)), dim3(256), 0,
+                               vspw_stream(stream), dz, z, x, mean, invstd, gamma, sums, 1.0 / count, chan_mask, rows,
+                               c, rows_per_image, relu, training, dx, dres);
+        }
+    }
+    if (dgamma || dbeta)
+        hipLaunchKernelGGL(bn_param_grads_kernel, dim3(vspw_cdiv(c, 256)), dim3(256), 0, vspw_stream(stream), sums,
+                           dgamma, dbeta, c);
+    return vspw_launch_status();
+}

@@ -1,0 +1,56 @@
+// Shared device/host helpers for the VSPW hot-path HIP library (gfx950 only).
+// All tensors are fp32, activations are NHWC ("pixel rows x channel columns").
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vspw_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define VSPW_WAVE 64
+
+static inline int vspw_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? VSPW_OK : VSPW_ELAUNCH;
+}
+
+static inline hipStream_t vspw_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int vspw_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Grid size for HBM-bound grid-stride kernels: enough blocks to fill 256 CUs x 8.
+static inline int vspw_stream_grid(long long work_items, int block) {
+    long long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;
+    return (int)g;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// PyTorch area_pixel_compute_source_index for align_corners=False (bilinear):
+// src = max(0, scale*(dst+0.5)-0.5); i0=floor(src); i1=i0+(i0<in-1); l1=src-i0.
+__device__ __forceinline__ void bilinear_src(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+    float src = scale * ((float)dst + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    l1 = src - (float)i0;
+    l1 = fminf(fmaxf(l1, 0.f), 1.f);
+}

@@ -1,0 +1,565 @@
+// Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// Replaces, for the VSPW hot path, every ATen conv2d call site of the reference:
+//   models/resnet.py:61-66,100-106,130 (stem / BasicBlock / Bottleneck convs),
+//   models/models.py:737-750 (dilated / de-strided variants made by _nostride_dilate),
+//   models/clip_psp.py:29,35,40,74,79; models/clip_ocr.py:43,56,58,62 (head convs),
+//   models/ocr_modules/spatial_ocr_block.py:208-244,351 (1x1 convs),
+// and their autograd backward (data gradient and weight gradient).
+//
+// Layout: activations NHWC fp32 ([pixel rows][channel cols]); weights [Cout][KH][KW][Cin]
+// (torch channels_last of an OIHW tensor), so both GEMM operands of the forward pass are
+// K-contiguous ("NT" GEMM):   Y[P][Cout] = im2col(X)[P][KH*KW*Cin] * W[Cout][KH*KW*Cin]^T
+// The data gradient is the same kernel with the gather run "backwards" (mode 1) over dY and a
+// [Cin][KH][KW][Cout] copy of the weights; the weight gradient is a "TN" GEMM whose reduction
+// runs over pixels (split-K across workgroups, deterministic two-pass reduction).
+//
+// Tile: 128x128 outputs per 256-thread workgroup (4 waves, each 64x64 = 2x2 MFMA 32x32 tiles),
+// BK = 32, operands staged global -> registers -> LDS (one LDS buffer, next tile's global loads
+// are in flight during the MFMA phase). fp32 MFMA issues one instruction per 64 cycles per SIMD,
+// so LDS and global bandwidth are far from binding; the kernel is MFMA-issue bound.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 32
+#define LDA 36  // padded LDS row stride (floats): 16 consecutive rows hit 16 distinct 16-B slots
+
+struct IgemmNT {
+    const float* src;   // gathered tensor [nb][h][w][c]
+    const float* wt;    // [nout][kdim]
+    const float* bias;  // [nout] or nullptr
+    float* dst;         // [m][ldd]
+    float* stat_part;   // optional [tiles_m][2][nout] per-tile column sum / sumsq (fused BN stats)
+    int nb, h, w, c;    // src dims
+    int oh, ow;         // pixel grid of the GEMM M dimension
+    int kh, kw, stride, pad, dil;
+    int mode;           // 0: forward gather, 1: data-gradient gather
+    int nout, ldd;
+    int m, kdim;
+    int vec;            // 1: float4 loads are legal (c % 4 == 0)
+};
+
+__device__ __forceinline__ bool nt_src_coord(const IgemmNT& p, int by, int bx, int ky, int kx, int& sy, int& sx) {
+    if (p.mode == 0) {
+        sy = by + ky * p.dil;
+        sx = bx + kx * p.dil;
+        return sy >= 0 && sy < p.h && sx >= 0 && sx < p.w;
+    } else {
+        int ty = by - ky * p.dil;
+        int tx = bx - kx * p.dil;
+        if (ty < 0 || tx < 0) return false;
+        if (p.stride != 1) {
+            if ((ty % p.stride) != 0 || (tx % p.stride) != 0) return false;
+            ty /= p.stride;
+            tx /= p.stride;
+        }
+        sy = ty;
+        sx = tx;
+        return sy < p.h && sx < p.w;
+    }
+}
+
+__global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
+    __shared__ __attribute__((aligned(16))) float As[BM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[BN * LDA];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int tiles_n = (p.nout + BN - 1) / BN;
+    const int tile_n = blockIdx.x % tiles_n;
+    const int tile_m = blockIdx.x / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int lrow = tid >> 3;       // 0..31
+    const int lcol = (tid & 7) * 4;  // 0,4,..,28
+
+    // Row (pixel) decode for the 4 A rows this thread stages; independent of k.
+    int a_img[4], a_by[4], a_bx[4];
+    bool a_ok[4];
+    const int ohw = p.oh * p.ow;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + lrow + 32 * i;
+        a_ok[i] = m < p.m;
+        int mm = a_ok[i] ? m : 0;
+        int n = mm / ohw;
+        int r = mm - n * ohw;
+        int oy = r / p.ow;
+        int ox = r - oy * p.ow;
+        a_img[i] = n;
+        if (p.mode == 0) {
+            a_by[i] = oy * p.stride - p.pad;
+            a_bx[i] = ox * p.stride - p.pad;
+        } else {
+            a_by[i] = oy + p.pad;
+            a_bx[i] = ox + p.pad;
+        }
+    }
+    bool b_ok[4];
+    size_t b_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int n = n0 + lrow + 32 * i;
+        b_ok[i] = n < p.nout;
+        b_off[i] = (size_t)(b_ok[i] ? n : 0) * (size_t)p.kdim;
+    }
+
+    f32x4 ra[4], rb[4];
+
+    auto load_tile = [&](int k0) {
+        const int k4 = k0 + lcol;
+        if (p.vec) {
+            const bool kin = k4 < p.kdim;  // kdim % 4 == 0 in the vector path
+            int tap = 0, ci = 0, ky = 0, kx = 0;
+            if (kin) {
+                tap = k4 / p.c;
+                ci = k4 - tap * p.c;
+                ky = tap / p.kw;
+                kx = tap - ky * p.kw;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                int sy, sx;
+                if (kin && a_ok[i] && nt_src_coord(p, a_by[i], a_bx[i], ky, kx, sy, sx)) {
+                    size_t off = (((size_t)a_img[i] * p.h + sy) * p.w + sx) * (size_t)p.c + ci;
+                    v = *reinterpret_cast<const f32x4*>(p.src + off);
+                }
+                ra[i] = v;
+                f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+                if (kin && b_ok[i]) wv = *reinterpret_cast<const f32x4*>(p.wt + b_off[i] + k4);
+                rb[i] = wv;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int k = k4 + e;
+                    if (k < p.kdim) {
+                        int tap = k / p.c;
+                        int ci = k - tap * p.c;
+                        int ky = tap / p.kw;
+                        int kx = tap - ky * p.kw;
+                        int sy, sx;
+                        if (a_ok[i] && nt_src_coord(p, a_by[i], a_bx[i], ky, kx, sy, sx)) {
+                            size_t off = (((size_t)a_img[i] * p.h + sy) * p.w + sx) * (size_t)p.c + ci;
+                            v[e] = p.src[off];
+                        }
+                        if (b_ok[i]) wv[e] = p.wt[b_off[i] + k];
+                    }
+                }
+                ra[i] = v;
+                rb[i] = wv;
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.kdim + BK - 1) / BK;
+    load_tile(0);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * LDA + lcol]) = ra[i];
+            *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * LDA + lcol]) = rb[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        // Each lane half (lh) owns 4 consecutive k of every 8-k chunk; MFMA step s pairs
+        // k = 8*kc + s (lanes 0-31) with k = 8*kc + 4 + s (lanes 32-63) for both operands.
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            f32x4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const f32x4*>(&As[(wm * 64 + i * 32 + l31) * LDA + kc * 8 + 4 * lh]);
+                b[i] = *reinterpret_cast<const f32x4*>(&Bs[(wn * 64 + i * 32 + l31) * LDA + kc * 8 + 4 * lh]);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // Epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        const bool cok = col < p.nout;
+        const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (cok && row < p.m) {
+                    float v = acc[i][j][r] + bv;
+                    p.dst[(size_t)row * p.ldd + col] = v;
+                    csum[j] += v;
+                    csq[j] += v * v;
+                }
+            }
+        }
+    }
+    if (p.stat_part != nullptr) {
+        // Per-tile column partial sums: lanes l and l^32 share a column; so do waves wm=0/1.
+        float* red = As;  // reuse LDS: [2 stats][2 wm][128 cols]
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float s = csum[j] + __shfl_xor(csum[j], 32, 64);
+            float q = csq[j] + __shfl_xor(csq[j], 32, 64);
+            if (lh == 0) {
+                int c = wn * 64 + j * 32 + l31;
+                red[(0 * 2 + wm) * 128 + c] = s;
+                red[(1 * 2 + wm) * 128 + c] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            int col = n0 + tid;
+            if (col < p.nout) {
+                float* out = p.stat_part + (size_t)tile_m * 2 * p.nout;
+                out[col] = red[0 * 128 + tid] + red[1 * 128 + tid];
+                out[p.nout + col] = red[2 * 128 + tid] + red[3 * 128 + tid];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient: dW[co][tap*C + ci] = sum_p dY[p][co] * X[src(p, tap)][ci]   (TN GEMM, split-K)
+// ---------------------------------------------------------------------------------------------
+struct IgemmTN {
+    const float* dy;  // [P][k]
+    const float* x;   // [nb][h][w][c]
+    float* part;      // [splits][k][ncols]
+    int nb, h, w, c;
+    int oh, ow;
+    int kh, kw, stride, pad, dil;
+    int k;       // Cout (GEMM M)
+    int ncols;   // kh*kw*c (GEMM N)
+    int P;       // nb*oh*ow (GEMM K)
+    int chunk;   // pixels per split (multiple of BK)
+    int vec_a;   // k % 4 == 0
+    int vec_b;   // c % 4 == 0
+};
+
+__global__ __launch_bounds__(256) void igemm_tn_kernel(IgemmTN p) {
+    __shared__ __attribute__((aligned(16))) float As[BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int tiles_n = (p.ncols + BN - 1) / BN;
+    const int tile_n = blockIdx.x % tiles_n;
+    const int tile_m = blockIdx.x / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int p_begin = split * p.chunk;
+    const int p_end = min(p.P, p_begin + p.chunk);
+
+    const int krow = tid >> 5;        // 0..7 (+8*i)
+    const int c4 = (tid & 31) * 4;    // 0..124
+
+    // B column decode (k independent).
+    int b_ky[4], b_kx[4], b_ci[4];
+    bool b_colok[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int n = n0 + c4 + e;
+        b_colok[e] = n < p.ncols;
+        int nn = b_colok[e] ? n : 0;
+        int tap = nn / p.c;
+        b_ci[e] = nn - tap * p.c;
+        b_ky[e] = tap / p.kw;
+        b_kx[e] = tap - b_ky[e] * p.kw;
+    }
+    const int ohw = p.oh * p.ow;
+
+    f32x4 ra[4], rb[4];
+    auto load_tile = [&](int pk0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pp = pk0 + krow + 8 * i;
+            f32x4 av = {0.f, 0.f, 0.f, 0.f};
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (pp < p_end) {
+                const int co = m0 + c4;
+                if (p.vec_a) {
+                    if (co < p.k) av = *reinterpret_cast<const f32x4*>(p.dy + (size_t)pp * p.k + co);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (co + e < p.k) av[e] = p.dy[(size_t)pp * p.k + co + e];
+                }
+                const int n = pp / ohw;
+                const int r = pp - n * ohw;
+                const int oy = r / p.ow;
+                const int ox = r - oy * p.ow;
+                const int by = oy * p.stride - p.pad, bx = ox * p.stride - p.pad;
+                if (p.vec_b) {
+                    if (b_colok[0]) {
+                        int sy = by + b_ky[0] * p.dil, sx = bx + b_kx[0] * p.dil;
+                        if (sy >= 0 && sy < p.h && sx >= 0 && sx < p.w)
+                            bv = *reinterpret_cast<const f32x4*>(
+                                p.x + (((size_t)n * p.h + sy) * p.w + sx) * (size_t)p.c + b_ci[0]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (b_colok[e]) {
+                            int sy = by + b_ky[e] * p.dil, sx = bx + b_kx[e] * p.dil;
+                            if (sy >= 0 && sy < p.h && sx >= 0 && sx < p.w)
+                                bv[e] = p.x[(((size_t)n * p.h + sy) * p.w + sx) * (size_t)p.c + b_ci[e]];
+                        }
+                    }
+                }
+            }
+            ra[i] = av;
+            rb[i] = bv;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p_end - p_begin + BK - 1) / BK;
+    if (nk > 0) load_tile(p_begin);
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&As[(krow + 8 * i) * BM + c4]) = ra[i];
+            *reinterpret_cast<f32x4*>(&Bs[(krow + 8 * i) * BN + c4]) = rb[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nk) load_tile(p_begin + (kt + 1) * BK);
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = As[(2 * s + lh) * BM + wm * 64 + i * 32 + l31];
+                b[i] = Bs[(2 * s + lh) * BN + wn * 64 + i * 32 + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float* out = p.part + (size_t)split * p.k * p.ncols;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= p.ncols) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < p.k) out[(size_t)row * p.ncols + col] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long long n, int splits) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float s = 0.f;
+        for (int z = 0; z < splits; ++z) s += part[(size_t)z * n + i];
+        out[i] = s;
+    }
+}
+
+// [r][t][s] -> [s][t][r]   (weights [Cout][taps][Cin] -> [Cin][taps][Cout])
+__global__ void weight_transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int T, int S) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int r0 = blockIdx.y * 32, s0 = blockIdx.x * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int r = r0 + i, s = s0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < R && s < S) ? in[((size_t)r * T + t) * S + s] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int s = s0 + i, r = r0 + threadIdx.x;
+        if (r < R && s < S) out[((size_t)s * T + t) * R + r] = tile[threadIdx.x][i];
+    }
+}
+
+// NCHW -> NHWC (and back) for the 3-channel images / class maps crossing the boundary.
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, long long HW) {
+    long long total = (long long)N * C * HW;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        int c = (int)(i % C);
+        long long r = i / C;
+        long long hw = r % HW;
+        long long n = r / HW;
+        out[i] = in[((size_t)n * C + c) * HW + hw];
+    }
+}
+
+static int conv_geometry_ok(const vspw_conv_desc* d) {
+    if (!d) return 0;
+    if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0 || d->k <= 0) return 0;
+    if (d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0) return 0;
+    int oh = (d->h + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+    int ow = (d->w + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+    return oh == d->oh && ow == d->ow && oh > 0 && ow > 0;
+}
+
+extern "C" size_t vspw_conv2d_stats_partials(const vspw_conv_desc* d) {
+    if (!d) return 0;
+    long long m = (long long)d->n * d->oh * d->ow;
+    return (size_t)((m + BM - 1) / BM);
+}
+
+extern "C" int vspw_conv2d_fwd(const vspw_conv_desc* d, const float* x, const float* w, const float* bias,
+                               float* y, float* stat_part, void* stream) {
+    if (!conv_geometry_ok(d) || !x || !w || !y) return VSPW_EINVAL;
+    IgemmNT p;
+    p.src = x; p.wt = w; p.bias = bias; p.dst = y; p.stat_part = stat_part;
+    p.nb = d->n; p.h = d->h; p.w = d->w; p.c = d->c;
+    p.oh = d->oh; p.ow = d->ow;
+    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.mode = 0;
+    p.nout = d->k; p.ldd = d->k;
+    long long m = (long long)d->n * d->oh * d->ow;
+    if (m > 0x7fffffffLL) return VSPW_EINVAL;
+    p.m = (int)m;
+    p.kdim = d->kh * d->kw * d->c;
+    p.vec = (d->c % 4 == 0) ? 1 : 0;
+    int tiles = vspw_cdiv(p.m, BM) * vspw_cdiv(p.nout, BN);
+    hipLaunchKernelGGL(igemm_nt_kernel, dim3(tiles), dim3(256), 0, vspw_stream(stream), p);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, const float* wT, float* dx,
+                                    void* stream) {
+    if (!conv_geometry_ok(d) || !dy || !wT || !dx) return VSPW_EINVAL;
+    IgemmNT p;
+    p.src = dy; p.wt = wT; p.bias = nullptr; p.dst = dx; p.stat_part = nullptr;
+    p.nb = d->n; p.h = d->oh; p.w = d->ow; p.c = d->k;   // gather over dY
+    p.oh = d->h; p.ow = d->w;                              // rows are input pixels
+    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.mode = 1;
+    p.nout = d->c; p.ldd = d->c;
+    long long m = (long long)d->n * d->h * d->w;
+    if (m > 0x7fffffffLL) return VSPW_EINVAL;
+    p.m = (int)m;
+    p.kdim = d->kh * d->kw * d->k;
+    p.vec = (d->k % 4 == 0) ? 1 : 0;
+    int tiles = vspw_cdiv(p.m, BM) * vspw_cdiv(p.nout, BN);
+    hipLaunchKernelGGL(igemm_nt_kernel, dim3(tiles), dim3(256), 0, vspw_stream(stream), p);
+    return vspw_launch_status();
+}
+
+static void wgrad_plan(const vspw_conv_desc* d, int& splits, int& chunk) {
+    long long P = (long long)d->n * d->oh * d->ow;
+    int ncols = d->kh * d->kw * d->c;
+    long long tiles = (long long)vspw_cdiv(d->k, BM) * vspw_cdiv(ncols, BN);
+    long long want = (1024 + tiles - 1) / tiles;
+    long long max_splits = (P + 255) / 256;
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    if (want > 512) want = 512;
+    long long ch = (P + want - 1) / want;
+    ch = ((ch + BK - 1) / BK) * BK;
+    splits = (int)((P + ch - 1) / ch);
+    chunk = (int)ch;
+}
+
+extern "C" size_t vspw_conv2d_bwd_weight_workspace(const vspw_conv_desc* d) {
+    if (!conv_geometry_ok(d)) return 0;
+    int splits, chunk;
+    wgrad_plan(d, splits, chunk);
+    if (splits <= 1) return 0;
+    return (size_t)splits * d->k * d->kh * d->kw * d->c * sizeof(float);
+}
+
+extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, const float* x, float* dw,
+                                      void* ws, size_t ws_bytes, void* stream) {
+    if (!conv_geometry_ok(d) || !dy || !x || !dw) return VSPW_EINVAL;
+    int splits, chunk;
+    wgrad_plan(d, splits, chunk);
+    size_t need = splits > 1 ? (size_t)splits * d->k * d->kh * d->kw * d->c * sizeof(float) : 0;
+    if (need > ws_bytes || (need > 0 && !ws)) return VSPW_EINVAL;
+    IgemmTN p;
+    p.dy = dy; p.x = x;
+    p.part = splits > 1 ? reinterpret_cast<float*>(ws) : dw;
+    p.nb = d->n; p.h = d->h; p.w = d->w; p.c = d->c;
+    p.oh = d->oh; p.ow = d->ow;
+    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.k = d->k;
+    p.ncols = d->kh * d->kw * d->c;
+    long long P = (long long)d->n * d->oh * d->ow;
+    if (P > 0x7fffffffLL) return VSPW_EINVAL;
+    p.P = (int)P;
+    p.chunk = chunk;
+    p.vec_a = (d->k % 4 == 0) ? 1 : 0;
+    p.vec_b = (d->c % 4 == 0) ? 1 : 0;
+    int tiles = vspw_cdiv(p.k, BM) * vspw_cdiv(p.ncols, BN);
+    hipLaunchKernelGGL(igemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
+    int st = vspw_launch_status();
+    if (st != VSPW_OK) return st;
+    if (splits > 1) {
+        long long n = (long long)p.k * p.ncols;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(vspw_stream_grid(n, 256)), dim3(256), 0, vspw_stream(stream),
+                           reinterpret_cast<const float*>(ws), dw, n, splits);
+        st = vspw_launch_status();
+    }
+    return st;
+}
+
+extern "C" int vspw_weight_transpose(const float* w, float* wT, int k, int taps, int c, void* stream) {
+    if (!w || !wT || k <= 0 || taps <= 0 || c <= 0) return VSPW_EINVAL;
+    dim3 grid(vspw_cdiv(c, 32), vspw_cdiv(k, 32), taps);
+    hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(32, 8), 0, vspw_stream(stream), w, wT, k, taps, c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_nchw_to_nhwc(const float* in, float* out, int n, int c, long long hw, void* stream) {
+    if (!in || !out || n <= 0 || c <= 0 || hw <= 0) return VSPW_EINVAL;
+    long long total = (long long)n * c * hw;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream), in,
+                       out, n, c, hw);
+    return vspw_launch_status();
+}

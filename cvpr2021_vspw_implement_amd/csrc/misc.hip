@@ -1,0 +1,278 @@
+// Small HBM-bound helpers: batched transpose, column sums (bias gradients), axpby, the NetWarp per-channel blend
+// and the optical-flow warp (grid_sample) of models/netwarp.py:12-37 with its adjoints.  NHWC fp32.
+#include "common.h"
+
+extern "C" int vspw_abi_version(void) { return VSPW_ABI_VERSION; }
+
+__global__ void transpose_batched_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.z * R * C;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < R && c < C) ? in[base + (size_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < R && c < C) out[base + (size_t)c * R + r] = tile[threadIdx.x][i];
+    }
+}
+
+#define CS_TX 32
+#define CS_TY 8
+// part[split][c] = sum over the split's rows of a[row][c] * (b ? b[row][c] : 1)
+__global__ __launch_bounds__(CS_TX * CS_TY) void colsum_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              long long rows, int c, double* __restrict__ part) {
+    __shared__ double red[CS_TY][CS_TX * 4];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int c0 = (blockIdx.x * CS_TX + tx) * 4;
+    double s[4] = {0, 0, 0, 0};
+    if (c0 < c) {
+        for (long long r = (long long)blockIdx.y * CS_TY + ty; r < rows; r += (long long)gridDim.y * CS_TY) {
+            const size_t off = (size_t)r * c + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < c) s[e] += b ? (double)a[off + e] * (double)b[off + e] : (double)a[off + e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[ty][tx * 4 + e] = s[e];
+    __syncthreads();
+    const int t = ty * CS_TX + tx;
+    if (t < CS_TX * 4) {
+        const int ch = blockIdx.x * CS_TX * 4 + t;
+        if (ch < c) {
+            double v = 0;
+#pragma unroll
+            for (int j = 0; j < CS_TY; ++j) v += red[j][t];
+            part[(size_t)blockIdx.y * c + ch] = v;
+        }
+    }
+}
+
+__global__ void colsum_final_kernel(const double* __restrict__ part, float* __restrict__ out, int splits, int c) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    double v = 0;
+    for (int z = 0; z < splits; ++z) v += part[(size_t)z * c + i];
+    out[i] = (float)v;
+}
+
+__global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float a, float b) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) y[i] = a * x[i] + (b != 0.f ? b * y[i] : 0.f);
+}
+
+__global__ void chan_blend_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                      const float* __restrict__ w0, const float* __restrict__ w1,
+                                      float* __restrict__ out, long long rows, int c) {
+    const long long total = rows * c;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int ch = (int)(i % c);
+        out[i] = w0[ch] * a[i] + w1[ch] * b[i];
+    }
+}
+
+// out[i] = w[ch] * g[i]
+__global__ void chan_scale_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ out,
+                                  long long rows, int c) {
+    const long long total = rows * c;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) out[i] = w[(int)(i % c)] * g[i];
+}
+
+// ---- flow warp -------------------------------------------------------------------------------------------------
+// flowwarp(x, flo): vgrid = meshgrid + flo; g = 2*vgrid/max(dim-1,1) - 1; grid_sample(x, g, bilinear, zeros,
+// align_corners=False) i.e. pixel coordinate p = ((g+1)*dim - 1)/2.  Note the (dim-1) normalisation combined with
+// align_corners=False is a quirk of the reference that is kept on purpose.
+__device__ __forceinline__ void warp_coords(int ox, int oy, float fx, float fy, int w, int h, float& px, float& py) {
+    const float gx = 2.0f * ((float)ox + fx) / (float)max(w - 1, 1) - 1.0f;
+    const float gy = 2.0f * ((float)oy + fy) / (float)max(h - 1, 1) - 1.0f;
+    px = ((gx + 1.f) * (float)w - 1.f) * 0.5f;
+    py = ((gy + 1.f) * (float)h - 1.f) * 0.5f;
+}
+
+__global__ __launch_bounds__(256) void flowwarp_fwd_kernel(const float* __restrict__ x, const float* __restrict__ flow,
+                                                           float* __restrict__ y, int n, int h, int w, int c) {
+    const int lane = threadIdx.x & 63;
+    const long long total = (long long)n * h * w;
+    long long pix = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+    for (; pix < total; pix += stride) {
+        const int ox = (int)(pix % w);
+        long long r = pix / w;
+        const int oy = (int)(r % h);
+        const int img = (int)(r / h);
+        float px, py;
+        warp_coords(ox, oy, flow[pix * 2], flow[pix * 2 + 1], w, h, px, py);
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+        const float tx = px - fx0, ty = py - fy0;
+        const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
+        const bool vx0 = x0 >= 0 && x0 < w, vx1 = x1 >= 0 && x1 < w, vy0 = y0 >= 0 && y0 < h, vy1 = y1 >= 0 && y1 < h;
+        const float* base = x + (size_t)img * h * w * c;
+        for (int ch = lane; ch < c; ch += 64) {
+            float v = 0.f;
+            if (vy0 && vx0) v += w00 * base[((size_t)y0 * w + x0) * c + ch];
+            if (vy0 && vx1) v += w01 * base[((size_t)y0 * w + x1) * c + ch];
+            if (vy1 && vx0) v += w10 * base[((size_t)y1 * w + x0) * c + ch];
+            if (vy1 && vx1) v += w11 * base[((size_t)y1 * w + x1) * c + ch];
+            y[(size_t)pix * c + ch] = v;
+        }
+    }
+}
+
+// dx must be zeroed by the caller (scatter with atomics: the flow field is arbitrary, so there is no bounded gather).
+__global__ __launch_bounds__(256) void flowwarp_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ flow, float* __restrict__ dx,
+                                                           float* __restrict__ dflow, int n, int h, int w, int c) {
+    const int lane = threadIdx.x & 63;
+    const long long total = (long long)n * h * w;
+    long long pix = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long long stride = (long long)gridDim.x * (blockDim.x >> 6);
+    const float dpx = (float)w / (float)max(w - 1, 1);  // d px / d flow_x
+    const float dpy = (float)h / (float)max(h - 1, 1);
+    for (; pix < total; pix += stride) {
+        const int ox = (int)(pix % w);
+        long long r = pix / w;
+        const int oy = (int)(r % h);
+        const int img = (int)(r / h);
+        float px, py;
+        warp_coords(ox, oy, flow[pix * 2], flow[pix * 2 + 1], w, h, px, py);
+        const float fx0 = floorf(px), fy0 = floorf(py);
+        const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+        const float tx = px - fx0, ty = py - fy0;
+        const float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
+        const bool vx0 = x0 >= 0 && x0 < w, vx1 = x1 >= 0 && x1 < w, vy0 = y0 >= 0 && y0 < h, vy1 = y1 >= 0 && y1 < h;
+        const size_t ib = (size_t)img * h * w * c;
+        float gxs = 0.f, gys = 0.f;
+        for (int ch = lane; ch < c; ch += 64) {
+            const float g = dy[(size_t)pix * c + ch];
+            float v00 = 0.f, v01 = 0.f, v10 = 0.f, v11 = 0.f;
+            if (vy0 && vx0) {
+                const size_t o = ib + ((size_t)y0 * w + x0) * c + ch;
+                v00 = x[o];
+                if (dx) atomicAdd(&dx[o], w00 * g);
+            }
+            if (vy0 && vx1) {
+                const size_t o = ib + ((size_t)y0 * w + x1) * c + ch;
+                v01 = x[o];
+                if (dx) atomicAdd(&dx[o], w01 * g);
+            }
+            if (vy1 && vx0) {
+                const size_t o = ib + ((size_t)y1 * w + x0) * c + ch;
+                v10 = x[o];
+                if (dx) atomicAdd(&dx[o], w10 * g);
+            }
+            if (vy1 && vx1) {
+                const size_t o = ib + ((size_t)y1 * w + x1) * c + ch;
+                v11 = x[o];
+                if (dx) atomicAdd(&dx[o], w11 * g);
+            }
+            gxs += g * ((v01 - v00) * (1.f - ty) + (v11 - v10) * ty);
+            gys += g * ((v10 - v00) * (1.f - tx) + (v11 - v01) * tx);
+        }
+        if (dflow) {
+            gxs = wave_sum(gxs);
+            gys = wave_sum(gys);
+            if (lane == 0) {
+                dflow[pix * 2] = gxs * dpx;
+                dflow[pix * 2 + 1] = gys * dpy;
+            }
+        }
+    }
+}
+
+static void colsum_plan(long long rows, int c, int& gx, int& gy) {
+    gx = vspw_cdiv(c, CS_TX * 4);
+    long long want = (2048 + gx - 1) / gx;
+    long long maxy = (rows + CS_TY - 1) / CS_TY;
+    if (want > maxy) want = maxy;
+    if (want < 1) want = 1;
+    gy = (int)want;
+}
+
+extern "C" size_t vspw_colsum_workspace(long long rows, int c) {
+    if (rows <= 0 || c <= 0) return 0;
+    int gx, gy;
+    colsum_plan(rows, c, gx, gy);
+    return (size_t)gy * c * sizeof(double);
+}
+
+extern "C" int vspw_colsum_prod(const float* a, const float* b, float* out, long long rows, int c, void* ws,
+                                size_t ws_bytes, void* stream) {
+    if (!a || !out || rows <= 0 || c <= 0) return VSPW_EINVAL;
+    int gx, gy;
+    colsum_plan(rows, c, gx, gy);
+    if (!ws || ws_bytes < (size_t)gy * c * sizeof(double)) return VSPW_EINVAL;
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(CS_TX, CS_TY), 0, vspw_stream(stream), a, b, rows, c, part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(vspw_cdiv(c, 256)), dim3(256), 0, vspw_stream(stream), part, out, gy,
+                       c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_colsum(const float* a, float* out, long long rows, int c, void* ws, size_t ws_bytes,
+                           void* stream) {
+    return vspw_colsum_prod(a, nullptr, out, rows, c, ws, ws_bytes, stream);
+}
+
+extern "C" int vspw_transpose_batched(const float* in, float* out, int b, int r, int c, void* stream) {
+    if (!in || !out || b <= 0 || r <= 0 || c <= 0 || b > 65535) return VSPW_EINVAL;
+    dim3 grid(vspw_cdiv(c, 32), vspw_cdiv(r, 32), b);
+    hipLaunchKernelGGL(transpose_batched_kernel, grid, dim3(32, 8), 0, vspw_stream(stream), in, out, r, c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_axpby(const float* x, float* y, long long n, float a, float b, void* stream) {
+    if (!x || !y || n <= 0) return VSPW_EINVAL;
+    hipLaunchKernelGGL(axpby_kernel, dim3(vspw_stream_grid(n, 256)), dim3(256), 0, vspw_stream(stream), x, y, n, a, b);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_chan_blend_fwd(const float* a, const float* b, const float* w0, const float* w1, float* out,
+                                   long long rows, int c, void* stream) {
+    if (!a || !b || !w0 || !w1 || !out || rows <= 0 || c <= 0) return VSPW_EINVAL;
+    hipLaunchKernelGGL(chan_blend_fwd_kernel, dim3(vspw_stream_grid(rows * c, 256)), dim3(256), 0, vspw_stream(stream),
+                       a, b, w0, w1, out, rows, c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_chan_scale(const float* g, const float* w, float* out, long long rows, int c, void* stream) {
+    if (!g || !w || !out || rows <= 0 || c <= 0) return VSPW_EINVAL;
+    hipLaunchKernelGGL(chan_scale_kernel, dim3(vspw_stream_grid(rows * c, 256)), dim3(256), 0, vspw_stream(stream), g,
+                       w, out, rows, c);
+    return vspw_launch_status();
+}
+
+static int pixel_wave_grid(long long items) {
+    long long g = (items + 3) / 4;
+    if (g < 1) g = 1;
+    if (g > 256 * 16) g = 256 * 16;
+    return (int)g;
+}
+
+extern "C" int vspw_flowwarp_fwd(const float* x, const float* flow, float* y, int n, int h, int w, int c,
+                                 void* stream) {
+    if (!x || !flow || !y || n <= 0 || h <= 0 || w <= 0 || c <= 0) return VSPW_EINVAL;
+    hipLaunchKernelGGL(flowwarp_fwd_kernel, dim3(pixel_wave_grid((long long)n * h * w)), dim3(256), 0,
+                       vspw_stream(stream), x, flow, y, n, h, w, c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_flowwarp_bwd(const float* dy, const float* x, const float* flow, float* dx, float* dflow, int n,
+                                 int h, int w, int c, void* stream) {
+    if (!dy || !x || !flow || n <= 0 || h <= 0 || w <= 0 || c <= 0) return VSPW_EINVAL;
+    if (dx) {
+        hipError_t e = hipMemsetAsync(dx, 0, (size_t)n * h * w * c * sizeof(float), vspw_stream(stream));
+        if (e != hipSuccess) return VSPW_ELAUNCH;
+    }
+    hipLaunchKernelGGL(flowwarp_bwd_kernel, dim3(pixel_wave_grid((long long)n * h * w)), dim3(256), 0,
+                       vspw_stream(stream), dy, x, flow, dx, dflow, n, h, w, c);
+    return vspw_launch_status();
+}

@@ -1,0 +1,251 @@
+// Pooling kernels (NHWC fp32, HBM-bound gathers; no atomics: every adjoint is a gather).
+//   maxpool 3x3/s2/p1       : models/resnet.py:109 (stem)
+//   adaptive average pool   : models/clip_psp.py:85-87,160-166; models/models.py:947,972 (PPM pyramid)
+//   temporal mean over T    : models/clip_psp.py:181-188 (Temporal Context Blending of TCB-PSP),
+//                             models/ocr_modules/spatial_ocr_block.py:108-109 (TCB-OCR context mean)
+#include "common.h"
+
+// ---- max pool ------------------------------------------------------------------------------------
+// ATen scans the window row-major and keeps the FIRST maximum (strict '>' , NaN propagates); the winning tap
+// index is stored so that the backward pass routes the gradient exactly like the reference.
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          uint8_t* __restrict__ idx, int n, int h, int w, int c,
+                                                          int oh, int ow) {
+    const long long total = (long long)n * oh * ow * c;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int ch = (int)(i % c);
+        long long r = i / c;
+        const int ox = (int)(r % ow);
+        r /= ow;
+        const int oy = (int)(r % oh);
+        const int img = (int)(r / oh);
+        float best = -INFINITY;
+        int bi = -1;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if (iy < 0 || iy >= h) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if (ix < 0 || ix >= w) continue;
+                const float v = x[(((size_t)img * h + iy) * w + ix) * c + ch];
+                if (bi < 0 || v > best || v != v) {
+                    best = v;
+                    bi = ky * 3 + kx;
+                }
+            }
+        }
+        y[i] = best;
+        idx[i] = (uint8_t)bi;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                          float* __restrict__ dx, int n, int h, int w, int c, int oh,
+                                                          int ow) {
+    const long long total = (long long)n * h * w * c;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int ch = (int)(i % c);
+        long long r = i / c;
+        const int ix = (int)(r % w);
+        r /= w;
+        const int iy = (int)(r % h);
+        const int img = (int)(r / h);
+        float g = 0.f;
+        // windows containing (iy, ix): oy with oy*2-1+ky == iy, ky in 0..2
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + 1 - ky;
+            if (ty < 0 || (ty & 1)) continue;
+            const int oy = ty >> 1;
+            if (oy >= oh) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + 1 - kx;
+                if (tx < 0 || (tx & 1)) continue;
+                const int ox = tx >> 1;
+                if (ox >= ow) continue;
+                const size_t o = (((size_t)img * oh + oy) * ow + ox) * c + ch;
+                if (idx[o] == (uint8_t)(ky * 3 + kx)) g += dy[o];
+            }
+        }
+        dx[i] = g;
+    }
+}
+
+// ---- adaptive average pool ---------------------------------------------------------------------------
+// bin i covers [floor(i*H/s), ceil((i+1)*H/s)) (ATen start_index/end_index); bins overlap when s does not divide H.
+__device__ __forceinline__ int bin_start(int i, int in, int s) { return (int)(((long long)i * in) / s); }
+__device__ __forceinline__ int bin_end(int i, int in, int s) { return (int)((((long long)(i + 1)) * in + s - 1) / s); }
+
+#define AP_TX 64
+#define AP_TY 4
+__global__ __launch_bounds__(AP_TX * AP_TY) void adaptive_avgpool_fwd_kernel(const float* __restrict__ x,
+                                                                            float* __restrict__ y, int n, int h, int w,
+                                                                            int c, int s) {
+    __shared__ float red[AP_TY][AP_TX * 4];
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    const int bin = blockIdx.y;
+    const int img = blockIdx.z;
+    const int by = bin / s, bx = bin - by * s;
+    const int y0 = bin_start(by, h, s), y1 = bin_end(by, h, s);
+    const int x0 = bin_start(bx, w, s), x1 = bin_end(bx, w, s);
+    const int bw = x1 - x0;
+    const int cnt = (y1 - y0) * bw;
+    const int c0 = (blockIdx.x * AP_TX + tx) * 4;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < c) {
+        for (int p = ty; p < cnt; p += AP_TY) {
+            const int py = y0 + p / bw, px = x0 + p % bw;
+            const float* src = x + (((size_t)img * h + py) * w + px) * c + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < c) a[e] += src[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[ty][tx * 4 + e] = a[e];
+    __syncthreads();
+    if (ty == 0 && c0 < c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c0 + e < c) {
+                float v = red[0][tx * 4 + e];
+#pragma unroll
+                for (int j = 1; j < AP_TY; ++j) v += red[j][tx * 4 + e];
+                y[(((size_t)img * s + by) * s + bx) * c + c0 + e] = v / (float)cnt;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                   int n, int h, int w, int c, int s, int accumulate) {
+    const long long total = (long long)n * h * w * c;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int ch = (int)(i % c);
+        long long r = i / c;
+        const int ix = (int)(r % w);
+        r /= w;
+        const int iy = (int)(r % h);
+        const int img = (int)(r / h);
+        float g = 0.f;
+        // candidate bins: those whose [start,end) contains the coordinate (at most 2 per axis)
+        int byc = (int)(((long long)iy * s) / h);
+        int bxc = (int)(((long long)ix * s) / w);
+        for (int by = max(0, byc - 1); by <= min(s - 1, byc + 1); ++by) {
+            const int y0 = bin_start(by, h, s), y1 = bin_end(by, h, s);
+            if (iy < y0 || iy >= y1) continue;
+            for (int bx = max(0, bxc - 1); bx <= min(s - 1, bxc + 1); ++bx) {
+                const int x0 = bin_start(bx, w, s), x1 = bin_end(bx, w, s);
+                if (ix < x0 || ix >= x1) continue;
+                const float cnt = (float)((y1 - y0) * (x1 - x0));
+                g += dy[(((size_t)img * s + by) * s + bx) * c + ch] / cnt;
+            }
+        }
+        dx[i] = accumulate ? dx[i] + g : g;
+    }
+}
+
+// ---- temporal mean ---------------------------------------------------------------------------------
+// x is [T][B][inner] (frames stacked frame-major along the batch, as torch.cat(clip_imgs) makes them).
+// The reference concatenates [current, others...] and takes torch.mean over that axis; fp32 summation order
+// here is t = T-1 (current frame, the LAST chunk of the batch) first, then t = 0..T-2, as the reference's cat.
+__global__ __launch_bounds__(256) void temporal_mean_fwd_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ wts, float* __restrict__ y,
+                                                                int T, int B, long long inner) {
+    const long long total = (long long)B * inner;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float invT = 1.f / (float)T;
+    for (; i < total; i += stride) {
+        const long long b = i / inner;
+        float a = 0.f;
+        for (int j = 0; j < T; ++j) {
+            const int t = (j == 0) ? (T - 1) : (j - 1);
+            float v = x[(size_t)t * total + i];
+            if (wts) v *= wts[b * T + j];
+            a += v;
+        }
+        y[i] = a * invT;
+    }
+}
+
+__global__ __launch_bounds__(256) void temporal_mean_bwd_kernel(const float* __restrict__ dy,
+                                                                const float* __restrict__ wts, float* __restrict__ dx,
+                                                                int T, int B, long long inner) {
+    const long long total = (long long)B * inner;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float invT = 1.f / (float)T;
+    for (; i < total; i += stride) {
+        const long long b = i / inner;
+        const float g = dy[i] * invT;
+        for (int j = 0; j < T; ++j) {
+            const int t = (j == 0) ? (T - 1) : (j - 1);
+            dx[(size_t)t * total + i] = wts ? g * wts[b * T + j] : g;
+        }
+    }
+}
+
+extern "C" int vspw_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int oh,
+                                     int ow, void* stream) {
+    if (!x || !y || !idx || n <= 0 || h <= 0 || w <= 0 || c <= 0) return VSPW_EINVAL;
+    if (oh != (h + 2 - 3) / 2 + 1 || ow != (w + 2 - 3) / 2 + 1) return VSPW_EINVAL;
+    long long total = (long long)n * oh * ow * c;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream), x, y,
+                       idx, n, h, w, c, oh, ow);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c,
+                                     int oh, int ow, void* stream) {
+    if (!dy || !dx || !idx || n <= 0 || h <= 0 || w <= 0 || c <= 0) return VSPW_EINVAL;
+    if (oh != (h + 2 - 3) / 2 + 1 || ow != (w + 2 - 3) / 2 + 1) return VSPW_EINVAL;
+    long long total = (long long)n * h * w * c;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream), dy,
+                       idx, dx, n, h, w, c, oh, ow);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_adaptive_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int s, void* stream) {
+    if (!x || !y || n <= 0 || h <= 0 || w <= 0 || c <= 0 || s <= 0 || n > 65535) return VSPW_EINVAL;
+    dim3 grid(vspw_cdiv(c, AP_TX * 4), s * s, n);
+    hipLaunchKernelGGL(adaptive_avgpool_fwd_kernel, grid, dim3(AP_TX, AP_TY), 0, vspw_stream(stream), x, y, n, h, w, c,
+                       s);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_adaptive_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int s,
+                                         int accumulate, void* stream) {
+    if (!dy || !dx || n <= 0 || h <= 0 || w <= 0 || c <= 0 || s <= 0) return VSPW_EINVAL;
+    long long total = (long long)n * h * w * c;
+    hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0,
+                       vspw_stream(stream), dy, dx, n, h, w, c, s, accumulate);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_temporal_mean_fwd(const float* x, const float* wts, float* y, int T, int B, long long inner,
+                                      void* stream) {
+    if (!x || !y || T <= 0 || B <= 0 || inner <= 0) return VSPW_EINVAL;
+    long long total = (long long)B * inner;
+    hipLaunchKernelGGL(temporal_mean_fwd_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream),
+                       x, wts, y, T, B, inner);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_temporal_mean_bwd(const float* dy, const float* wts, float* dx, int T, int B, long long inner,
+                                      void* stream) {
+    if (!dy || !dx || T <= 0 || B <= 0 || inner <= 0) return VSPW_EINVAL;
+    long long total = (long long)B * inner;
+    hipLaunchKernelGGL(temporal_mean_bwd_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream),
+                       dy, wts, dx, T, B, inner);
+    return vspw_launch_status();
+}

@@ -1,0 +1,311 @@
+"""ModelBuilder, dilated ResNet encoder, PPM decoders and the per-frame SegmentationModule on the HIP kernels.
+
+Surface mirrors reference models/models.py: ModelBuilder.build_encoder/build_decoder (:512-656), ResnetDilated
+(:707-767), PPM / PPMDeepsup / PPMDeepsup_clip / PPM_clip (:889-1083), SegmentationModule (:74-111) — same
+arguments, same feed_dict keys, same state_dict keys, same exceptions — so train.py / test.py / train_clip2.py /
+test_clip2.py drop in.  Heads that SURVEY.md §8 marks out of scope are importable stubs that raise at construction.
+"""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import nn as vnn
+from .. import ops
+from . import resnet
+
+BatchNorm2d = vnn.SynchronizedBatchNorm2d
+BN_MOMENTUM = 0.1
+
+
+def nll_ignore_index(crit):
+    """The drivers pass crit = nn.NLLLoss(ignore_index=255) (train_clip2.py:282); the fused loss kernel implements
+    exactly that criterion (mean over non-ignored pixels)."""
+    if not isinstance(crit, nn.NLLLoss):
+        raise NotImplementedError("only nn.NLLLoss criteria are implemented on the HIP path (got %r)" % (crit,))
+    if crit.weight is not None or crit.reduction != "mean":
+        raise NotImplementedError("NLLLoss with class weights / non-mean reduction is not on the VSPW hot path")
+    return int(crit.ignore_index)
+
+
+class SegmentationModuleBase(nn.Module):
+    def pixel_acc(self, pred, label):
+        """reference models/models.py:65-71 (kept for API parity; the fused loss kernel returns the same number)."""
+        _, preds = torch.max(pred, dim=1)
+        valid = (label >= 0).long()
+        acc_sum = torch.sum(valid * (preds == label).long())
+        pixel_sum = torch.sum(valid)
+        return acc_sum.float() / (pixel_sum.float() + 1e-10)
+
+
+class SegmentationModule(SegmentationModuleBase):
+    def __init__(self, net_enc, net_dec, crit, deep_sup_scale=None):
+        super().__init__()
+        self.encoder = net_enc
+        self.decoder = net_dec
+        self.crit = crit
+        self.deep_sup_scale = deep_sup_scale
+
+    def forward(self, feed_dict=None, segSize=None):
+        if feed_dict is None:
+            return torch.zeros((0, self.args.num_class, 480, 720)).cuda()
+        feats = self.encoder(feed_dict["img_data"], return_feature_maps=True)
+        if segSize is not None:  # inference
+            return self.decoder(feats, segSize=segSize)
+        ignore = nll_ignore_index(self.crit)
+        label = feed_dict["seg_label"]
+        if self.deep_sup_scale is not None:
+            pred, pred_deepsup = self.decoder(feats)
+        else:
+            pred = self.decoder(feats)
+        loss, acc = ops.seg_nll(pred, label, ignore, want_acc=True, from_logits=False)
+        if self.deep_sup_scale is not None:
+            loss_deepsup, _ = ops.seg_nll(pred_deepsup, label, ignore, want_acc=False, from_logits=False)
+            loss = loss + loss_deepsup * self.deep_sup_scale
+        return loss, acc
+
+
+def _stub(name, why="is outside the MI355X hot-path scope (SURVEY.md §8)"):
+    class _Stub(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError("%s %s" % (name, why))
+
+    _Stub.__name__ = name
+    return _Stub
+
+
+ClipWarpNet = _stub("ClipWarpNet")
+SegmentationModule_clip = _stub("SegmentationModule_clip")
+SegmentationModule_allclip = _stub("SegmentationModule_allclip")
+Conv_LSTM_Model = _stub("Conv_LSTM_Model")
+Non_local = _stub("Non_local")
+
+
+class ModelBuilder:
+    @staticmethod
+    def weights_init(m):
+        classname = m.__class__.__name__
+        if classname.find("Conv") != -1:
+            nn.init.kaiming_normal_(m.weight.data)
+        elif classname.find("BatchNorm") != -1:
+            m.weight.data.fill_(1.0)
+            m.bias.data.fill_(1e-4)
+
+    @staticmethod
+    def build_encoder(arch="resnet50dilated", fc_dim=512, weights="", args=None):
+        arch = arch.lower()
+        plain = {"resnet18": resnet.resnet18, "resnet50": resnet.resnet50, "resnet101": resnet.resnet101}
+        if arch in ("resnet34", "resnet34dilated"):
+            raise NotImplementedError
+        if arch in plain:
+            net_encoder = Resnet(plain[arch](pretrained=False))
+        elif arch.endswith("dilated") and arch[: -len("dilated")] in plain:
+            net_encoder = ResnetDilated(plain[arch[: -len("dilated")]](pretrained=False), dilate_scale=8)
+        elif arch in ("mobilenetv2dilated", "resnext101", "hrnetv2", "hrnetv2_clip", "hrnetv2_clip2"):
+            raise NotImplementedError("encoder '%s' is outside the MI355X hot-path scope (SURVEY.md §8)" % arch)
+        else:
+            raise Exception("Architecture undefined!")
+        if len(weights) > 0:
+            print("Loading weights for net_encoder")
+            net_encoder.load_state_dict(torch.load(weights, map_location=lambda storage, loc: storage), strict=False)
+        return net_encoder
+
+    @staticmethod
+    def build_decoder(arch="ppm_deepsup", fc_dim=512, num_class=150, weights="", use_softmax=False):
+        arch = arch.lower()
+        if arch == "ppm":
+            net_decoder = PPM(num_class=num_class, fc_dim=fc_dim, use_softmax=use_softmax)
+        elif arch == "ppm_deepsup":
+            net_decoder = PPMDeepsup(num_class=num_class, fc_dim=fc_dim, use_softmax=use_softmax)
+        elif arch == "ppm_deepsup_clip":
+            net_decoder = PPMDeepsup_clip(num_class=num_class, fc_dim=fc_dim, use_softmax=use_softmax)
+        elif arch == "ppm_clip":
+            net_decoder = PPM_clip(num_class=num_class, fc_dim=fc_dim, use_softmax=use_softmax)
+        elif arch == "nonlocal2d":
+            from .non_local_models import Non_local2d
+
+            net_decoder = Non_local2d(num_class=num_class)
+        elif arch == "ocrnet_deepsup":
+            from .ocrnet import SpatialOCRNet
+
+            net_decoder = SpatialOCRNet(num_class=num_class)
+        elif arch in ("c1_deepsup", "c1", "upernet_lite", "upernet", "deeplab"):
+            raise NotImplementedError("decoder '%s' is outside the MI355X hot-path scope (SURVEY.md §8)" % arch)
+        else:
+            raise Exception("Architecture undefined!")
+        net_decoder.apply(ModelBuilder.weights_init)
+        if len(weights) > 0:
+            print("Loading weights for net_decoder")
+            net_decoder.load_state_dict(torch.load(weights, map_location=lambda storage, loc: storage), strict=False)
+        return net_decoder
+
+
+def conv3x3_bn_relu(in_planes, out_planes, stride=1):
+    return vnn.FusedSequential(
+        vnn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False),
+        BatchNorm2d(out_planes),
+        nn.ReLU(inplace=True),
+    )
+
+
+def _encoder_stages(net, x, return_feature_maps):
+    conv_out = []
+    x = net.stem(x)
+    for name in ("layer1", "layer2", "layer3", "layer4"):
+        x = getattr(net, name)(x)
+        conv_out.append(x)
+    if return_feature_maps:
+        return conv_out
+    return [x]
+
+
+class _ResnetTrunk(nn.Module):
+    """Takes the stem and the four stages of a ResNet, drops avgpool/fc (reference models/models.py:660-705)."""
+
+    def _adopt(self, orig_resnet):
+        for name in ("conv1", "bn1", "relu1", "conv2", "bn2", "relu2", "conv3", "bn3", "relu3", "maxpool",
+                     "layer1", "layer2", "layer3", "layer4"):
+            setattr(self, name, getattr(orig_resnet, name))
+
+    stem = resnet.ResNet.stem
+
+    def forward(self, x, return_feature_maps=False):
+        return _encoder_stages(self, x, return_feature_maps)
+
+
+class Resnet(_ResnetTrunk):
+    def __init__(self, orig_resnet):
+        super().__init__()
+        self._adopt(orig_resnet)
+
+
+class ResnetDilated(_ResnetTrunk):
+    def __init__(self, orig_resnet, dilate_scale=8):
+        super().__init__()
+        if dilate_scale == 8:
+            orig_resnet.layer3.apply(partial(self._nostride_dilate, dilate=2))
+            orig_resnet.layer4.apply(partial(self._nostride_dilate, dilate=4))
+        elif dilate_scale == 16:
+            orig_resnet.layer4.apply(partial(self._nostride_dilate, dilate=2))
+        self._adopt(orig_resnet)
+
+    def _nostride_dilate(self, m, dilate):
+        # reference models/models.py:737-750: de-stride, then dilate every 3x3 of the stage
+        if isinstance(m, nn.Conv2d):
+            if m.stride == (2, 2):
+                m.stride = (1, 1)
+                if m.kernel_size == (3, 3):
+                    m.dilation = (dilate // 2, dilate // 2)
+                    m.padding = (dilate // 2, dilate // 2)
+            elif m.kernel_size == (3, 3):
+                m.dilation = (dilate, dilate)
+                m.padding = (dilate, dilate)
+
+
+class _PPMBase(nn.Module):
+    """Shared pyramid: ModuleList of Sequential(AdaptiveAvgPool2d(s), Conv1x1, BN, ReLU) (keys ppm.i.{1,2}.*)."""
+
+    def _build_ppm(self, fc_dim, pool_scales):
+        self.pool_scales = tuple(pool_scales)
+        ppm = []
+        for scale in pool_scales:
+            ppm.append(nn.Sequential(
+                vnn.AdaptiveAvgPool2d(scale),
+                vnn.Conv2d(fc_dim, 512, kernel_size=1, bias=False),
+                BatchNorm2d(512),
+                nn.ReLU(inplace=True),
+            ))
+        self.ppm = nn.ModuleList(ppm)
+
+    def _pyramid(self, conv5):
+        pooled = ops.pyramid_pool(conv5, self.pool_scales, 1, None)
+        branches = [vnn.conv_bn_act(p, seq[1], seq[2], relu=True) for p, seq in zip(pooled, self.ppm)]
+        return ops.ppm_concat(conv5, branches)
+
+
+def _cls_head(fc_dim, n_scales, num_class):
+    return vnn.FusedSequential(
+        vnn.Conv2d(fc_dim + n_scales * 512, 512, kernel_size=3, padding=1, bias=False),
+        BatchNorm2d(512),
+        nn.ReLU(inplace=True),
+        nn.Dropout2d(0.1),
+        vnn.Conv2d(512, num_class, kernel_size=1),
+    )
+
+
+class PPM(_PPMBase):
+    def __init__(self, num_class=150, fc_dim=4096, use_softmax=False, pool_scales=(1, 2, 3, 6)):
+        super().__init__()
+        self.use_softmax = use_softmax
+        self._build_ppm(fc_dim, pool_scales)
+        self.conv_last = _cls_head(fc_dim, len(pool_scales), num_class)
+
+    def forward(self, conv_out, segSize=None):
+        x = self.conv_last(self._pyramid(conv_out[-1]))
+        if self.use_softmax:
+            return ops.upsample_softmax(x, segSize)
+        return ops.log_softmax_channels(x)
+
+
+class PPMDeepsup(_PPMBase):
+    def __init__(self, num_class=150, fc_dim=4096, use_softmax=False, pool_scales=(1, 2, 3, 6)):
+        super().__init__()
+        self.use_softmax = use_softmax
+        self._build_ppm(fc_dim, pool_scales)
+        self.cbr_deepsup = conv3x3_bn_relu(fc_dim // 2, fc_dim // 4, 1)
+        self.conv_last_ = _cls_head(fc_dim, len(pool_scales), num_class)
+        self.conv_last_deepsup_ = vnn.Conv2d(fc_dim // 4, num_class, 1, 1, 0)
+        self.dropout_deepsup = nn.Dropout2d(0.1)
+
+    def _deepsup(self, conv4):
+        c, b = self.cbr_deepsup[0], self.cbr_deepsup[1]
+        y = vnn.conv_bn_act(conv4, c, b, relu=True, dropout=self.dropout_deepsup)
+        return self.conv_last_deepsup_(y)
+
+    def forward(self, conv_out, segSize=None):
+        x = self.conv_last_(self._pyramid(conv_out[-1]))
+        if segSize is not None:
+            return ops.upsample_softmax(x, segSize)
+        ds = self._deepsup(conv_out[-2])
+        return ops.log_softmax_channels(x), ops.log_softmax_channels(ds)
+
+
+class PPMDeepsup_clip(_PPMBase):
+    """NetWarp's decoder: returns (deepsup log-probs, 512-ch embedding, 4096-ch PPM concat)."""
+
+    def __init__(self, num_class=150, fc_dim=4096, use_softmax=False, pool_scales=(1, 2, 3, 6)):
+        super().__init__()
+        self.use_softmax = use_softmax
+        self._build_ppm(fc_dim, pool_scales)
+        self.cbr_deepsup = conv3x3_bn_relu(fc_dim // 2, fc_dim // 4, 1)
+        self.conv_last_ = vnn.FusedSequential(
+            vnn.Conv2d(fc_dim + len(pool_scales) * 512, 512, kernel_size=3, padding=1, bias=False),
+            BatchNorm2d(512),
+            nn.ReLU(inplace=True),
+        )
+        self.conv_last_deepsup_ = vnn.Conv2d(fc_dim // 4, num_class, 1, 1, 0)
+        self.dropout_deepsup = nn.Dropout2d(0.1)
+
+    def forward(self, conv_out):
+        ppm_out = self._pyramid(conv_out[-1])
+        emb = self.conv_last_(ppm_out)
+        c, b = self.cbr_deepsup[0], self.cbr_deepsup[1]
+        ds = vnn.conv_bn_act(conv_out[-2], c, b, relu=True, dropout=self.dropout_deepsup)
+        ds = ops.log_softmax_channels(self.conv_last_deepsup_(ds))
+        return ds, emb, ppm_out
+
+
+class PPM_clip(_PPMBase):
+    def __init__(self, num_class=150, fc_dim=4096, use_softmax=False, pool_scales=(1, 2, 3, 6)):
+        super().__init__()
+        self.use_softmax = use_softmax
+        self._build_ppm(fc_dim, pool_scales)
+        self.cbr_deepsup = conv3x3_bn_relu(fc_dim // 2, fc_dim // 4, 1)
+        self.conv_last_ = vnn.FusedSequential(
+            vnn.Conv2d(fc_dim + len(pool_scales) * 512, 512, kernel_size=3, padding=1, bias=False),
+            BatchNorm2d(512),
+            nn.ReLU(inplace=True),
+        )
+
+    def forward(self, conv_out):
+        return self.conv_last_(self._pyramid(conv_out[-1]))

@@ -1,0 +1,134 @@
+"""Deep-stem ResNet-18/50/101 backbones on the HIP kernels.
+
+Same constructor surface, attribute names and state_dict keys as the reference's models/resnet.py:95-205
+(3x conv3x3 stem 3->64(s2)->64->128, max-pool, four stages, avgpool/fc_1 kept for key parity), but every block is
+executed as fused conv+BN(+residual)+ReLU kernel chains instead of separate ATen ops.
+"""
+import math
+
+import torch.nn as nn
+
+from .. import nn as vnn
+from .. import ops
+
+__all__ = ["ResNet", "resnet18", "resnet50", "resnet101", "BasicBlock", "Bottleneck"]
+
+BatchNorm2d = vnn.SynchronizedBatchNorm2d
+
+
+def conv3x3(in_planes, out_planes, stride=1):
+    return vnn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
+
+
+def _residual_branch(block, x):
+    if block.downsample is None:
+        return x
+    return vnn.conv_bn_act(x, block.downsample[0], block.downsample[1], relu=False)
+
+
+class BasicBlock(nn.Module):
+    """reference models/resnet.py:24-53"""
+
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = conv3x3(inplanes, planes, stride)
+        self.bn1 = BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3(planes, planes)
+        self.bn2 = BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        return vnn.conv_bn_act(out, self.conv2, self.bn2, relu=True, residual=_residual_branch(self, x))
+
+
+class Bottleneck(nn.Module):
+    """reference models/resnet.py:56-92 (stride sits on the 3x3)"""
+
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = vnn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = vnn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv3 = vnn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        out = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        out = vnn.conv_bn_act(out, self.conv2, self.bn2, relu=True)
+        return vnn.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=_residual_branch(self, x))
+
+
+class ResNet(nn.Module):
+    def __init__(self, block, layers, num_classes=146):
+        self.inplanes = 128
+        super().__init__()
+        self.conv1 = conv3x3(3, 64, stride=2)
+        self.bn1 = BatchNorm2d(64)
+        self.relu1 = nn.ReLU(inplace=True)
+        self.conv2 = conv3x3(64, 64)
+        self.bn2 = BatchNorm2d(64)
+        self.relu2 = nn.ReLU(inplace=True)
+        self.conv3 = conv3x3(64, 128)
+        self.bn3 = BatchNorm2d(128)
+        self.relu3 = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc_1 = nn.Linear(512 * block.expansion, num_classes)
+
+        for m in self.modules():  # reference models/resnet.py:118-124
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, math.sqrt(2.0 / n))
+            elif isinstance(m, BatchNorm2d):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                vnn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                BatchNorm2d(planes * block.expansion),
+            )
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def stem(self, x):
+        x = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        x = vnn.conv_bn_act(x, self.conv2, self.bn2, relu=True)
+        x = vnn.conv_bn_act(x, self.conv3, self.bn3, relu=True)
+        return ops.max_pool3x3s2(x)
+
+    def forward(self, x):
+        raise NotImplementedError("the ImageNet classifier head (avgpool + fc_1) is not on the VSPW hot path")
+
+
+def resnet18(pretrained=False, **kwargs):
+    return ResNet(BasicBlock, [2, 2, 2, 2], **kwargs)
+
+
+def resnet50(pretrained=False, **kwargs):
+    return ResNet(Bottleneck, [3, 4, 6, 3], **kwargs)
+
+
+def resnet101(pretrained=False, **kwargs):
+    return ResNet(Bottleneck, [3, 4, 23, 3], **kwargs)

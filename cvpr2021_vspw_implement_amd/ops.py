@@ -1,0 +1,964 @@
+"""Host-side operators of the VSPW hot path: thin autograd.Functions that launch the hand-written HIP kernels of
+libvspw_hip.so through its C ABI (include/vspw_hip.h).  PyTorch is used for device memory, streams and autograd
+bookkeeping only; every FLOP of these operators runs in csrc/*.hip.
+
+Tensors keep the reference's logical NCHW shapes but live in NHWC memory (torch channels_last), so `x.size()` reads
+like the reference while the kernels see [pixel rows][channel columns].
+
+There is no CPU fallback: a CPU tensor raises (SURVEY.md §8b "Errors").
+"""
+import ctypes
+
+import torch
+
+from . import _C
+from ._C import ConvDesc
+
+_vp = ctypes.c_void_p
+
+
+def _stream():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else _vp(t.data_ptr())
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            "%s: the VSPW hot path runs only through the HIP kernels on a GPU tensor (got device %s); "
+            "there is no CPU fallback" % (what, t.device)
+        )
+    if t.dtype != torch.float32:
+        raise RuntimeError("%s: fp32 tensors only (got %s)" % (what, t.dtype))
+
+
+def is_nhwc(x):
+    return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
+
+
+def to_nhwc(x):
+    """Logical NCHW tensor -> same logical tensor in NHWC memory (no-op when already so)."""
+    if is_nhwc(x):
+        return x
+    if x.dim() != 4:
+        raise RuntimeError("expected a 4-D NCHW tensor, got %s" % (tuple(x.shape),))
+    _require_gpu(x, "to_nhwc")
+    n, c, h, w = x.shape
+    out = empty_nhwc(n, c, h, w, x.device)
+    if x.is_contiguous():
+        _C.call("vspw_nchw_to_nhwc", _p(x), _p(out), n, c, h * w, _stream())
+    else:  # arbitrary strides: let torch gather it (plumbing, not compute)
+        out.copy_(x)
+    return out
+
+
+def empty_nhwc(n, c, h, w, device, dtype=torch.float32):
+    return torch.empty((n, h, w, c), device=device, dtype=dtype).permute(0, 3, 1, 2)
+
+
+def _conv_desc(x, k, kh, kw, stride, pad, dil):
+    n, c, h, w = x.shape
+    oh = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    ow = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    return ConvDesc(n, h, w, c, oh, ow, k, kh, kw, stride, pad, dil)
+
+
+def _ws(nbytes, device):
+    return torch.empty((max(int(nbytes), 8) + 7) // 8, device=device, dtype=torch.float64)
+
+
+# --------------------------------------------------------------------------------------------------- conv
+def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False):
+    """x NHWC-memory [N,C,H,W]; w [K,C,KH,KW] in channels_last memory ([K][KH][KW][C])."""
+    _require_gpu(x, "conv2d")
+    x = to_nhwc(x)
+    if not is_nhwc(w):
+        w = w.contiguous(memory_format=torch.channels_last)
+    k, c, kh, kw = w.shape
+    if c != x.shape[1]:
+        raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (x.shape[1], c))
+    d = _conv_desc(x, k, kh, kw, stride, pad, dil)
+    y = empty_nhwc(d.n, k, d.oh, d.ow, x.device)
+    part = None
+    if want_stats:
+        tiles = _C.query("vspw_conv2d_stats_partials", ctypes.byref(d))
+        part = torch.empty((tiles, 2, k), device=x.device, dtype=torch.float32)
+    _C.call("vspw_conv2d_fwd", ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y), _p(part), _stream())
+    return y, part, d
+
+
+def conv2d_backward_data(dy, w, d):
+    k, c, kh, kw = w.shape
+    wT = torch.empty((c, kh, kw, k), device=w.device, dtype=torch.float32)
+    _C.call("vspw_weight_transpose", _p(w), _p(wT), k, kh * kw, c, _stream())
+    dx = empty_nhwc(d.n, d.c, d.h, d.w, dy.device)
+    _C.call("vspw_conv2d_bwd_data", ctypes.byref(d), _p(dy), _p(wT), _p(dx), _stream())
+    return dx
+
+
+def conv2d_backward_weight(dy, x, d):
+    dw = torch.empty((d.k, d.kh, d.kw, d.c), device=dy.device, dtype=torch.float32).permute(0, 3, 1, 2)
+    nbytes = _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d))
+    ws = _ws(nbytes, dy.device) if nbytes else None
+    _C.call("vspw_conv2d_bwd_weight", ctypes.byref(d), _p(dy), _p(x), _p(dw), _p(ws), nbytes, _stream())
+    return dw
+
+
+def colsum(a2d_rows, c, a, b=None):
+    nbytes = _C.query("vspw_colsum_workspace", a2d_rows, c)
+    ws = _ws(nbytes, a.device)
+    out = torch.empty(c, device=a.device, dtype=torch.float32)
+    _C.call("vspw_colsum_prod", _p(a), _p(b), _p(out), a2d_rows, c, _p(ws), nbytes, _stream())
+    return out
+
+
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d forward/backward on the implicit-GEMM MFMA kernels (csrc/conv_igemm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, dil):
+        x = to_nhwc(x)
+        y, _, d = conv2d_forward(x, w, bias, stride, pad, dil)
+        ctx.d = d
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        d = ctx.d
+        dy = to_nhwc(dy)
+        if not is_nhwc(w):
+            w = w.contiguous(memory_format=torch.channels_last)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_backward_data(dy, w, d)
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_backward_weight(dy, x, d)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(d.n * d.oh * d.ow, d.k, dy)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1):
+    return Conv2dFn.apply(x, w, bias, stride, pad, dil)
+
+
+# --------------------------------------------------------------------------------------------------- batch norm
+_sync_group = {"enabled": False, "group": None}
+
+
+def set_sync_bn(enabled, group=None):
+    """Enable the cross-rank exchange of BatchNorm statistics (SynchronizedBatchNorm semantics,
+    models/sync_batchnorm/batchnorm.py:110-150) over torch.distributed (RCCL on ROCm)."""
+    _sync_group["enabled"] = bool(enabled)
+    _sync_group["group"] = group
+
+
+def _sync_world():
+    if not _sync_group["enabled"]:
+        return 1
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1
+    return dist.get_world_size(_sync_group["group"])
+
+
+def _all_reduce_sums(sums):
+    import torch.distributed as dist
+
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_sync_group["group"])
+
+
+class BatchNormActFn(torch.autograd.Function):
+    """z = [relu](BN(x) [+ residual]) [* dropout2d mask]; training or eval statistics (csrc/bn.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, mask, training, momentum, eps, relu,
+                stat_part):
+        _require_gpu(x, "batch_norm")
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        rows = n * h * w
+        dev = x.device
+        st = _stream()
+        coef = torch.empty((4, c), device=dev, dtype=torch.float32)  # mean, invstd, scale, shift
+        mean, invstd, scale, shift = coef[0], coef[1], coef[2], coef[3]
+        count = float(rows)
+        world = 1
+        if training:
+            if rows * _sync_world() <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                                 % (tuple(x.shape),))
+            sums = torch.empty((2, c), device=dev, dtype=torch.float64)
+            if stat_part is not None:
+                _C.call("vspw_bn_reduce_partials_f32", _p(stat_part), stat_part.shape[0], c, _p(sums), st)
+            else:
+                nbytes = _C.query("vspw_bn_stats_workspace", rows, c)
+                ws = _ws(nbytes, dev)
+                _C.call("vspw_bn_stats", _p(x), rows, c, _p(sums), _p(ws), nbytes, st)
+            world = _sync_world()
+            if world > 1:
+                _all_reduce_sums(sums)
+                count = float(rows * world)
+            _C.call("vspw_bn_finalize", _p(sums), ctypes.c_double(count), _p(gamma), _p(beta), _p(running_mean),
+                    _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), c, st)
+        else:
+            _C.call("vspw_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(mean),
+                    _p(invstd), _p(scale), _p(shift), c, st)
+        if residual is not None:
+            residual = to_nhwc(residual)
+        z = empty_nhwc(n, c, h, w, dev)
+        _C.call("vspw_bn_apply", _p(x), _p(scale), _p(shift), _p(residual), _p(mask), _p(z), rows, c, h * w,
+                1 if relu else 0, st)
+        ctx.training = training
+        ctx.relu = relu
+        ctx.count = count
+        ctx.world = world
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, z if relu else None, gamma, coef, mask)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, z, gamma, coef, mask = ctx.saved_tensors
+        dz = to_nhwc(dz)
+        n, c, h, w = x.shape
+        rows = n * h * w
+        dev = x.device
+        st = _stream()
+        mean, invstd = coef[0], coef[1]
+        sums = torch.empty((2, c), device=dev, dtype=torch.float64)
+        nbytes = _C.query("vspw_bn_bwd_workspace", rows, c)
+        ws = _ws(nbytes, dev)
+        relu = 1 if ctx.relu else 0
+        _C.call("vspw_bn_bwd_reduce", _p(dz), _p(z), _p(x), _p(mean), _p(invstd), _p(mask), rows, c, h * w, relu,
+                _p(sums), _p(ws), nbytes, st)
+        dgamma = torch.empty(c, device=dev, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        dbeta = torch.empty(c, device=dev, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        if dgamma is not None or dbeta is not None:  # parameter gradients are the LOCAL sums
+            _C.call("vspw_bn_bwd_apply", _p(dz), _p(z), _p(x), _p(mean), _p(invstd), _p(gamma), _p(sums),
+                    ctypes.c_double(ctx.count), _p(mask), rows, c, h * w, relu, 1 if ctx.training else 0, None, None,
+                    _p(dgamma), _p(dbeta), st)
+        if ctx.training and ctx.world > 1:
+            _all_reduce_sums(sums)
+        dx = empty_nhwc(n, c, h, w, dev) if ctx.needs_input_grad[0] else None
+        dres = empty_nhwc(n, c, h, w, dev) if (ctx.has_res and ctx.needs_input_grad[5]) else None
+        if dx is not None or dres is not None:
+            _C.call("vspw_bn_bwd_apply", _p(dz), _p(z), _p(x), _p(mean), _p(invstd), _p(gamma), _p(sums),
+                    ctypes.c_double(ctx.count), _p(mask), rows, c, h * w, relu, 1 if ctx.training else 0, _p(dx),
+                    _p(dres), None, None, st)
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
+
+
+def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, mask=None, training=True, momentum=0.1,
+                   eps=1e-5, relu=False, stat_part=None):
+    return BatchNormActFn.apply(x, gamma, beta, running_mean, running_var, residual, mask, training, momentum, eps,
+                                relu, stat_part)
+
+
+class ConvBNActFn(torch.autograd.Function):
+    """conv2d -> BN(train/eval) -> [+residual] -> [ReLU] -> [Dropout2d mask] as ONE autograd node, with the
+    BatchNorm statistics accumulated in the convolution epilogue (no separate pass over the conv output)."""
+
+    @staticmethod
+    def forward(ctx, x, w, cbias, gamma, beta, running_mean, running_var, residual, mask, stride, pad, dil, training,
+                momentum, eps, relu):
+        _require_gpu(x, "conv_bn_act")
+        x = to_nhwc(x)
+        fuse_stats = training and _sync_world() == 1
+        y, part, d = conv2d_forward(x, w, cbias, stride, pad, dil, want_stats=fuse_stats)
+        n, c, h, wd = y.shape
+        rows = n * h * wd
+        dev = x.device
+        st = _stream()
+        coef = torch.empty((4, c), device=dev, dtype=torch.float32)
+        mean, invstd, scale, shift = coef[0], coef[1], coef[2], coef[3]
+        count = float(rows)
+        world = 1
+        if training:
+            if rows * _sync_world() <= 1:
+                raise ValueError("Expected more than 1 value per channel when training, got input size %s"
+                                 % (tuple(y.shape),))
+            sums = torch.empty((2, c), device=dev, dtype=torch.float64)
+            if part is not None:
+                _C.call("vspw_bn_reduce_partials_f32", _p(part), part.shape[0], c, _p(sums), st)
+            else:
+                nbytes = _C.query("vspw_bn_stats_workspace", rows, c)
+                ws = _ws(nbytes, dev)
+                _C.call("vspw_bn_stats", _p(y), rows, c, _p(sums), _p(ws), nbytes, st)
+            world = _sync_world()
+            if world > 1:
+                _all_reduce_sums(sums)
+                count = float(rows * world)
+            _C.call("vspw_bn_finalize", _p(sums), ctypes.c_double(count), _p(gamma), _p(beta), _p(running_mean),
+                    _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), c, st)
+        else:
+            _C.call("vspw_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(mean),
+                    _p(invstd), _p(scale), _p(shift), c, st)
+        if residual is not None:
+            residual = to_nhwc(residual)
+        z = empty_nhwc(n, c, h, wd, dev)
+        _C.call("vspw_bn_apply", _p(y), _p(scale), _p(shift), _p(residual), _p(mask), _p(z), rows, c, h * wd,
+                1 if relu else 0, st)
+        ctx.d = d
+        ctx.training = training
+        ctx.relu = relu
+        ctx.count = count
+        ctx.world = world
+        ctx.has_res = residual is not None
+        ctx.has_cbias = cbias is not None
+        ctx.save_for_backward(x, w, y, z if relu else None, gamma, coef, mask)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w, y, z, gamma, coef, mask = ctx.saved_tensors
+        d = ctx.d
+        dz = to_nhwc(dz)
+        n, c, h, wd = y.shape
+        rows = n * h * wd
+        dev = y.device
+        st = _stream()
+        mean, invstd = coef[0], coef[1]
+        relu = 1 if ctx.relu else 0
+        train = 1 if ctx.training else 0
+        sums = torch.empty((2, c), device=dev, dtype=torch.float64)
+        nbytes = _C.query("vspw_bn_bwd_workspace", rows, c)
+        ws = _ws(nbytes, dev)
+        _C.call("vspw_bn_bwd_reduce", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(mask), rows, c, h * wd, relu,
+                _p(sums), _p(ws), nbytes, st)
+        dgamma = torch.empty(c, device=dev, dtype=torch.float32) if ctx.needs_input_grad[3] else None
+        dbeta = torch.empty(c, device=dev, dtype=torch.float32) if ctx.needs_input_grad[4] else None
+        if dgamma is not None or dbeta is not None:
+            _C.call("vspw_bn_bwd_apply", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums),
+                    ctypes.c_double(ctx.count), _p(mask), rows, c, h * wd, relu, train, None, None, _p(dgamma),
+                    _p(dbeta), st)
+        if ctx.training and ctx.world > 1:
+            _all_reduce_sums(sums)
+        dy = empty_nhwc(n, c, h, wd, dev)
+        dres = empty_nhwc(n, c, h, wd, dev) if (ctx.has_res and ctx.needs_input_grad[7]) else None
+        _C.call("vspw_bn_bwd_apply", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums),
+                ctypes.c_double(ctx.count), _p(mask), rows, c, h * wd, relu, train, _p(dy), _p(dres), None, None, st)
+        if not is_nhwc(w):
+            w = w.contiguous(memory_format=torch.channels_last)
+        dx = dw = dcb = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_backward_data(dy, w, d)
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_backward_weight(dy, x, d)
+        if ctx.has_cbias and ctx.needs_input_grad[2]:
+            dcb = colsum(rows, c, dy)
+        return (dx, dw, dcb, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None)
+
+
+def conv_bn_act(x, w, cbias, gamma, beta, running_mean, running_var, residual=None, mask=None, stride=1, pad=0,
+                dil=1, training=True, momentum=0.1, eps=1e-5, relu=True):
+    return ConvBNActFn.apply(x, w, cbias, gamma, beta, running_mean, running_var, residual, mask, stride, pad, dil,
+                             training, momentum, eps, relu)
+
+
+# --------------------------------------------------------------------------------------------------- pooling
+class MaxPool3x3s2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x, "max_pool")
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        oh, ow = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+        y = empty_nhwc(n, c, oh, ow, x.device)
+        idx = torch.empty((n, oh, ow, c), device=x.device, dtype=torch.uint8)
+        _C.call("vspw_maxpool3x3s2_fwd", _p(x), _p(y), _p(idx), n, h, w, c, oh, ow, _stream())
+        ctx.shape = (n, c, h, w, oh, ow)
+        ctx.save_for_backward(idx)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n, c, h, w, oh, ow = ctx.shape
+        dy = to_nhwc(dy)
+        dx = empty_nhwc(n, c, h, w, dy.device)
+        _C.call("vspw_maxpool3x3s2_bwd", _p(dy), _p(idx), _p(dx), n, h, w, c, oh, ow, _stream())
+        return dx
+
+
+def max_pool3x3s2(x):
+    return MaxPool3x3s2Fn.apply(x)
+
+
+class PyramidPoolFn(torch.autograd.Function):
+    """AdaptiveAvgPool2d at every pyramid scale over all frames, then (optionally) the Temporal-Context-Blending
+    mean over the T frames of each clip (models/clip_psp.py:157-188).  Returns one [B,C,s,s] tensor per scale."""
+
+    @staticmethod
+    def forward(ctx, x, scales, T, wts):
+        _require_gpu(x, "pyramid_pool")
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        if n % T != 0:
+            raise RuntimeError("pyramid_pool: batch %d is not a multiple of T=%d" % (n, T))
+        B = n // T
+        st = _stream()
+        outs = []
+        for s in scales:
+            pooled = empty_nhwc(n, c, s, s, x.device)
+            _C.call("vspw_adaptive_avgpool_fwd", _p(x), _p(pooled), n, h, w, c, s, st)
+            if T > 1:
+                blended = empty_nhwc(B, c, s, s, x.device)
+                _C.call("vspw_temporal_mean_fwd", _p(pooled), _p(wts), _p(blended), T, B, s * s * c, st)
+                outs.append(blended)
+            else:
+                outs.append(pooled)
+        ctx.meta = (n, c, h, w, tuple(scales), T)
+        ctx.save_for_backward(wts)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (wts,) = ctx.saved_tensors
+        n, c, h, w, scales, T = ctx.meta
+        B = n // T
+        st = _stream()
+        dev = grads[0].device
+        dx = empty_nhwc(n, c, h, w, dev)
+        first = True
+        for s, g in zip(scales, grads):
+            if g is None:
+                continue
+            g = to_nhwc(g)
+            if T > 1:
+                gp = empty_nhwc(n, c, s, s, dev)
+                _C.call("vspw_temporal_mean_bwd", _p(g), _p(wts), _p(gp), T, B, s * s * c, st)
+            else:
+                gp = g
+            _C.call("vspw_adaptive_avgpool_bwd", _p(gp), _p(dx), n, h, w, c, s, 0 if first else 1, st)
+            first = False
+        if first:
+            dx.zero_()
+        return dx, None, None, None
+
+
+def pyramid_pool(x, scales, T=1, wts=None):
+    return PyramidPoolFn.apply(x, tuple(scales), T, wts)
+
+
+class PPMConcatFn(torch.autograd.Function):
+    """torch.cat([conv5] + [bilinear_up(branch_i)], dim=1) written straight into one NHWC buffer
+    (models/clip_psp.py:45-53)."""
+
+    @staticmethod
+    def forward(ctx, x, *branches):
+        _require_gpu(x, "ppm_concat")
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        st = _stream()
+        ctot = c + sum(b.shape[1] for b in branches)
+        out = empty_nhwc(n, ctot, h, w, x.device)
+        _C.call("vspw_copy_channels", _p(x), _p(out), n * h * w, c, c, 0, ctot, 0, st)
+        off = c
+        metas = []
+        for b in branches:
+            b = to_nhwc(b)
+            bn_, bc, bh, bw = b.shape
+            if bn_ != n:
+                raise RuntimeError("ppm_concat: batch mismatch")
+            _C.call("vspw_bilinear_fwd", _p(b), _p(out), n, bh, bw, h, w, bc, bc, 0, ctot, off, st)
+            metas.append((bc, bh, bw, off))
+            off += bc
+        ctx.meta = (n, c, h, w, ctot, metas)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w, ctot, metas = ctx.meta
+        g = to_nhwc(g)
+        st = _stream()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = empty_nhwc(n, c, h, w, g.device)
+            _C.call("vspw_copy_channels", _p(g), _p(dx), n * h * w, c, ctot, 0, c, 0, st)
+        outs = [dx]
+        for i, (bc, bh, bw, off) in enumerate(metas):
+            if not ctx.needs_input_grad[1 + i]:
+                outs.append(None)
+                continue
+            db = empty_nhwc(n, bc, bh, bw, g.device)
+            _C.call("vspw_bilinear_bwd", _p(g), _p(db), n, bh, bw, h, w, bc, bc, 0, ctot, off, st)
+            outs.append(db)
+        return tuple(outs)
+
+
+def ppm_concat(x, branches):
+    return PPMConcatFn.apply(x, *branches)
+
+
+class BilinearFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        _require_gpu(x, "interpolate")
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        oh, ow = int(size[0]), int(size[1])
+        y = empty_nhwc(n, c, oh, ow, x.device)
+        _C.call("vspw_bilinear_fwd", _p(x), _p(y), n, h, w, oh, ow, c, c, 0, c, 0, _stream())
+        ctx.meta = (n, c, h, w, oh, ow)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w, oh, ow = ctx.meta
+        g = to_nhwc(g)
+        dx = empty_nhwc(n, c, h, w, g.device)
+        _C.call("vspw_bilinear_bwd", _p(g), _p(dx), n, h, w, oh, ow, c, c, 0, c, 0, _stream())
+        return dx, None
+
+
+def interpolate_bilinear(x, size):
+    return BilinearFn.apply(x, tuple(size))
+
+
+# --------------------------------------------------------------------------------------------------- softmax / loss
+class ChannelSoftmaxFn(torch.autograd.Function):
+    """(log_)softmax over dim=1 of an NCHW-logical / NHWC-memory tensor."""
+
+    @staticmethod
+    def forward(ctx, x, log):
+        _require_gpu(x, "softmax")
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, h, w, x.device)
+        _C.call("vspw_softmax_lastdim_fwd", _p(x), _p(y), n * h * w, c, 1.0, 1 if log else 0, _stream())
+        ctx.log = log
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = to_nhwc(g)
+        n, c, h, w = y.shape
+        dx = empty_nhwc(n, c, h, w, y.device)
+        _C.call("vspw_softmax_lastdim_bwd", _p(g), _p(y), _p(dx), n * h * w, c, 1.0, 1 if ctx.log else 0, _stream())
+        return dx, None
+
+
+def log_softmax_channels(x):
+    return ChannelSoftmaxFn.apply(x, True)
+
+
+def softmax_channels(x):
+    return ChannelSoftmaxFn.apply(x, False)
+
+
+def _labels_i64(label, n, H, W):
+    """[n,1,H,W] or [n,H,W] float/long labels -> contiguous int64 [n,H,W] (the reference's label.squeeze(1).long())."""
+    if label.dim() == 4:
+        label = label.squeeze(1)
+    if tuple(label.shape) != (n, H, W):
+        raise RuntimeError("label shape %s does not match (%d,%d,%d)" % (tuple(label.shape), n, H, W))
+    return label.long().contiguous()
+
+
+class SegNLLFn(torch.autograd.Function):
+    """loss, acc = NLLLoss(ignore)(bilinear_up(logp), label), pixel_acc(...)  without materialising the up-sampled
+    tensor.  `from_logits`: logp = log_softmax(x) is computed here and the backward returns d/d logits."""
+
+    @staticmethod
+    def forward(ctx, x, label, ignore_index, want_acc, from_logits):
+        _require_gpu(x, "seg_nll")
+        x = to_nhwc(x)
+        n, k, h, w = x.shape
+        H, W = label.shape[-2], label.shape[-1]
+        lab = _labels_i64(label, n, H, W)
+        st = _stream()
+        if from_logits:
+            logp = empty_nhwc(n, k, h, w, x.device)
+            _C.call("vspw_softmax_lastdim_fwd", _p(x), _p(logp), n * h * w, k, 1.0, 1, st)
+        else:
+            logp = x
+        out = torch.empty(4, device=x.device, dtype=torch.float64)
+        _C.call("vspw_zero_f64", _p(out), 4, st)
+        _C.call("vspw_seg_nll_fwd", _p(logp), _p(lab), _p(out), n, h, w, k, H, W, int(ignore_index),
+                1 if want_acc else 0, st)
+        loss = (out[0] / out[1]).float()
+        acc = (out[2] / (out[3] + 1e-10)).float()
+        ctx.meta = (n, k, h, w, H, W, int(ignore_index), bool(from_logits))
+        ctx.save_for_backward(logp, lab, out)
+        ctx.mark_non_differentiable(acc)
+        return loss, acc
+
+    @staticmethod
+    def backward(ctx, gloss, gacc):
+        logp, lab, out = ctx.saved_tensors
+        n, k, h, w, H, W, ignore, from_logits = ctx.meta
+        g = gloss.reshape(1).float().contiguous()
+        dx = empty_nhwc(n, k, h, w, logp.device)
+        _C.call("vspw_seg_nll_bwd", _p(logp), _p(lab), _p(out), _p(g), _p(dx), n, h, w, k, H, W, ignore,
+                1 if from_logits else 0, _stream())
+        return dx, None, None, None, None
+
+
+def seg_nll(x, label, ignore_index=255, want_acc=True, from_logits=True):
+    return SegNLLFn.apply(x, label, ignore_index, want_acc, from_logits)
+
+
+def upsample_softmax(logits, size):
+    """Inference head: softmax(bilinear_up(logits, size), dim=1) -> [n,K,H,W] (NHWC memory). No autograd."""
+    _require_gpu(logits, "upsample_softmax")
+    logits = to_nhwc(logits.detach())
+    n, k, h, w = logits.shape
+    H, W = int(size[0]), int(size[1])
+    probs = empty_nhwc(n, k, H, W, logits.device)
+    _C.call("vspw_upsample_softmax", _p(logits), _p(probs), n, h, w, k, H, W, _stream())
+    return probs
+
+
+# --------------------------------------------------------------------------------------------------- batched GEMMs
+def _gemm_nt(a, bt):
+    """a [M,K] row-major, bt [N,K] row-major -> a @ bt^T [M,N]   (1x1 conv forward kernel)."""
+    M, K = a.shape
+    N = bt.shape[0]
+    d = ConvDesc(1, M, 1, K, M, 1, N, 1, 1, 1, 0, 1)
+    y = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    _C.call("vspw_conv2d_fwd", ctypes.byref(d), _p(a), _p(bt), None, _p(y), None, _stream())
+    return y
+
+
+def _gemm_tn(a, b):
+    """a [R,M], b [R,N] -> a^T @ b [M,N]   (1x1 conv weight-gradient kernel)."""
+    R, M = a.shape
+    N = b.shape[1]
+    d = ConvDesc(1, R, 1, N, R, 1, M, 1, 1, 1, 0, 1)
+    y = torch.empty((M, N), device=a.device, dtype=torch.float32)
+    nbytes = _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d))
+    ws = _ws(nbytes, a.device) if nbytes else None
+    _C.call("vspw_conv2d_bwd_weight", ctypes.byref(d), _p(a), _p(b), _p(y), _p(ws), nbytes, _stream())
+    return y
+
+
+def _transpose(a):
+    """[B,R,C] -> [B,C,R] contiguous."""
+    B, R, C = a.shape
+    out = torch.empty((B, C, R), device=a.device, dtype=torch.float32)
+    _C.call("vspw_transpose_batched", _p(a), _p(out), B, R, C, _stream())
+    return out
+
+
+class BmmNTFn(torch.autograd.Function):
+    """c[b] = a[b] @ bt[b]^T ; a [B,M,K], bt [B,N,K] (both contiguous, K fastest)."""
+
+    @staticmethod
+    def forward(ctx, a, bt):
+        _require_gpu(a, "bmm_nt")
+        a = a.contiguous()
+        bt = bt.contiguous()
+        ctx.save_for_backward(a, bt)
+        return torch.stack([_gemm_nt(a[i], bt[i]) for i in range(a.shape[0])], 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, bt = ctx.saved_tensors
+        g = g.contiguous()
+        B = a.shape[0]
+        da = dbt = None
+        if ctx.needs_input_grad[0]:  # da = g @ bt : NT with (bt^T) [K,N] rows
+            btT = _transpose(bt)  # [B,K,N]
+            da = torch.stack([_gemm_nt(g[i], btT[i]) for i in range(B)], 0)
+        if ctx.needs_input_grad[1]:  # dbt = g^T @ a  [N,K]
+            dbt = torch.stack([_gemm_tn(g[i], a[i]) for i in range(B)], 0)
+        return da, dbt
+
+
+class BmmTNFn(torch.autograd.Function):
+    """c[b] = a[b]^T @ b[b] ; a [B,R,M], b [B,R,N] -> [B,M,N]."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _require_gpu(a, "bmm_tn")
+        a = a.contiguous()
+        b = b.contiguous()
+        ctx.save_for_backward(a, b)
+        return torch.stack([_gemm_tn(a[i], b[i]) for i in range(a.shape[0])], 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()  # [B,M,N]
+        B = a.shape[0]
+        da = db = None
+        if ctx.needs_input_grad[0]:  # da [R,M] = b [R,N] @ g[M,N]^T
+            da = torch.stack([_gemm_nt(b[i], g[i]) for i in range(B)], 0)
+        if ctx.needs_input_grad[1]:  # db [R,N] = a [R,M] @ g [M,N] = NT(a, g^T [N,M])
+            gT = _transpose(g)
+            db = torch.stack([_gemm_nt(a[i], gT[i]) for i in range(B)], 0)
+        return da, db
+
+
+def bmm_nt(a, bt):
+    return BmmNTFn.apply(a, bt)
+
+
+def bmm_tn(a, b):
+    return BmmTNFn.apply(a, b)
+
+
+class TransposeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a):
+        _require_gpu(a, "transpose")
+        return _transpose(a.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return _transpose(g.contiguous())
+
+
+def transpose_last2(a):
+    return TransposeFn.apply(a)
+
+
+class RowSoftmaxFn(torch.autograd.Function):
+    """softmax(alpha * x, dim=-1) for a contiguous [..., K] tensor."""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        _require_gpu(x, "row_softmax")
+        x = x.contiguous()
+        k = x.shape[-1]
+        rows = x.numel() // k
+        y = torch.empty_like(x)
+        _C.call("vspw_softmax_lastdim_fwd", _p(x), _p(y), rows, k, float(alpha), 0, _stream())
+        ctx.alpha = float(alpha)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        k = y.shape[-1]
+        dx = torch.empty_like(y)
+        _C.call("vspw_softmax_lastdim_bwd", _p(g), _p(y), _p(dx), y.numel() // k, k, ctx.alpha, 0, _stream())
+        return dx, None
+
+
+def row_softmax(x, alpha=1.0):
+    return RowSoftmaxFn.apply(x, alpha)
+
+
+class PixelSoftmaxFn(torch.autograd.Function):
+    """softmax over the pixel axis of [B,HW,K] (dim=1)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha):
+        _require_gpu(x, "pixel_softmax")
+        x = x.contiguous()
+        B, HW, K = x.shape
+        y = torch.empty_like(x)
+        _C.call("vspw_softmax_pixels_fwd", _p(x), _p(y), B, HW, K, float(alpha), _stream())
+        ctx.alpha = float(alpha)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        B, HW, K = y.shape
+        dx = torch.empty_like(y)
+        _C.call("vspw_softmax_pixels_bwd", _p(g), _p(y), _p(dx), B, HW, K, ctx.alpha, _stream())
+        return dx, None
+
+
+def pixel_softmax(x, alpha=1.0):
+    return PixelSoftmaxFn.apply(x, alpha)
+
+
+class TemporalMeanFn(torch.autograd.Function):
+    """x [T*B, ...] stacked frame-major -> mean over T, reference order [current(last chunk), others...]."""
+
+    @staticmethod
+    def forward(ctx, x, T):
+        _require_gpu(x, "temporal_mean")
+        x = x.contiguous()
+        n = x.shape[0]
+        B = n // T
+        inner = x.numel() // n
+        y = torch.empty((B,) + tuple(x.shape[1:]), device=x.device, dtype=torch.float32)
+        _C.call("vspw_temporal_mean_fwd", _p(x), None, _p(y), T, B, inner, _stream())
+        ctx.meta = (T, B, inner, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        T, B, inner, shape = ctx.meta
+        g = g.contiguous()
+        dx = torch.empty(shape, device=g.device, dtype=torch.float32)
+        _C.call("vspw_temporal_mean_bwd", _p(g), None, _p(dx), T, B, inner, _stream())
+        return dx, None
+
+
+def temporal_mean(x, T):
+    return TemporalMeanFn.apply(x, T)
+
+
+# --------------------------------------------------------------------------------------------------- netwarp pieces
+class FlowWarpFn(torch.autograd.Function):
+    """flowwarp(x, flo) of models/netwarp.py:12-37; flo is [B,2,H,W] (x-displacement, y-displacement)."""
+
+    @staticmethod
+    def forward(ctx, x, flo):
+        _require_gpu(x, "flowwarp")
+        x = to_nhwc(x)
+        flo = to_nhwc(flo)
+        n, c, h, w = x.shape
+        if tuple(flo.shape) != (n, 2, h, w):
+            raise RuntimeError("flowwarp: flow shape %s does not match input %s" % (tuple(flo.shape), tuple(x.shape)))
+        y = empty_nhwc(n, c, h, w, x.device)
+        _C.call("vspw_flowwarp_fwd", _p(x), _p(flo), _p(y), n, h, w, c, _stream())
+        ctx.save_for_backward(x, flo)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, flo = ctx.saved_tensors
+        g = to_nhwc(g)
+        n, c, h, w = x.shape
+        dx = empty_nhwc(n, c, h, w, x.device) if ctx.needs_input_grad[0] else None
+        dflo = empty_nhwc(n, 2, h, w, x.device) if ctx.needs_input_grad[1] else None
+        _C.call("vspw_flowwarp_bwd", _p(g), _p(x), _p(flo), _p(dx), _p(dflo), n, h, w, c, _stream())
+        return dx, dflo
+
+
+def flowwarp(x, flo):
+    return FlowWarpFn.apply(x, flo)
+
+
+class ChanBlendFn(torch.autograd.Function):
+    """w0[c]*a + w1[c]*b (models/netwarp.py:201,216-217)."""
+
+    @staticmethod
+    def forward(ctx, a, b, w0, w1):
+        _require_gpu(a, "chan_blend")
+        a = to_nhwc(a)
+        b = to_nhwc(b)
+        n, c, h, w = a.shape
+        out = empty_nhwc(n, c, h, w, a.device)
+        _C.call("vspw_chan_blend_fwd", _p(a), _p(b), _p(w0), _p(w1), _p(out), n * h * w, c, _stream())
+        ctx.save_for_backward(a, b, w0, w1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, w0, w1 = ctx.saved_tensors
+        g = to_nhwc(g)
+        n, c, h, w = a.shape
+        rows = n * h * w
+        st = _stream()
+        da = db = dw0 = dw1 = None
+        if ctx.needs_input_grad[0]:
+            da = empty_nhwc(n, c, h, w, a.device)
+            _C.call("vspw_chan_scale", _p(g), _p(w0), _p(da), rows, c, st)
+        if ctx.needs_input_grad[1]:
+            db = empty_nhwc(n, c, h, w, a.device)
+            _C.call("vspw_chan_scale", _p(g), _p(w1), _p(db), rows, c, st)
+        if ctx.needs_input_grad[2]:
+            dw0 = colsum(rows, c, g, a)
+        if ctx.needs_input_grad[3]:
+            dw1 = colsum(rows, c, g, b)
+        return da, db, dw0, dw1
+
+
+def chan_blend(a, b, w0, w1):
+    return ChanBlendFn.apply(a, b, w0, w1)
+
+
+class ChannelCatFn(torch.autograd.Function):
+    """torch.cat(tensors, dim=1) for NHWC-memory tensors (strided channel-slice copies)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        _require_gpu(xs[0], "channel_cat")
+        xs = [to_nhwc(x) for x in xs]
+        n, _, h, w = xs[0].shape
+        ctot = sum(x.shape[1] for x in xs)
+        out = empty_nhwc(n, ctot, h, w, xs[0].device)
+        st = _stream()
+        off = 0
+        widths = []
+        for x in xs:
+            if (x.shape[0], x.shape[2], x.shape[3]) != (n, h, w):
+                raise RuntimeError("channel_cat: shape mismatch")
+            c = x.shape[1]
+            _C.call("vspw_copy_channels", _p(x), _p(out), n * h * w, c, c, 0, ctot, off, st)
+            widths.append(c)
+            off += c
+        ctx.meta = (n, h, w, ctot, widths)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, ctot, widths = ctx.meta
+        g = to_nhwc(g)
+        st = _stream()
+        outs = []
+        off = 0
+        for i, c in enumerate(widths):
+            if ctx.needs_input_grad[i]:
+                d = empty_nhwc(n, c, h, w, g.device)
+                _C.call("vspw_copy_channels", _p(g), _p(d), n * h * w, c, ctot, off, c, 0, st)
+                outs.append(d)
+            else:
+                outs.append(None)
+            off += c
+        return tuple(outs)
+
+
+def channel_cat(xs):
+    return ChannelCatFn.apply(*xs)
+
+
+def pixels_view(x):
+    """NHWC-memory [N,C,H,W] -> zero-copy [N, H*W, C] view (rows = pixels)."""
+    x = to_nhwc(x)
+    n, c, h, w = x.shape
+    return x.permute(0, 2, 3, 1).reshape(n, h * w, c)
+
+
+def from_pixels(p, h, w):
+    """[N, H*W, C] contiguous -> logical [N,C,H,W] in NHWC memory (zero-copy)."""
+    n, hw, c = p.shape
+    return p.reshape(n, h, w, c).permute(0, 3, 1, 2)
+
+
+class ScaleFn(torch.autograd.Function):
+    """y = a * x for a dense tensor of any layout (elementwise on the underlying storage order)."""
+
+    @staticmethod
+    def forward(ctx, x, a):
+        _require_gpu(x, "scale")
+        if not x.is_contiguous():
+            x = x.contiguous()
+        y = torch.empty_like(x)
+        _C.call("vspw_axpby", _p(x), _p(y), x.numel(), float(a), 0.0, _stream())
+        ctx.a = float(a)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        dx = torch.empty_like(g)
+        _C.call("vspw_axpby", _p(g), _p(dx), g.numel(), ctx.a, 0.0, _stream())
+        return dx, None
+
+
+def scale(x, a):
+    return ScaleFn.apply(x, a)

@@ -1,0 +1,182 @@
+/*
+ * vspw_hip.h — C ABI of libvspw_hip.so, the hand-written HIP (gfx950 / MI355X) compute library behind the
+ * ModelBuilder / SegmentationModule / Clip_PSP / ClipOCRNet surface of sssdddwww2/CVPR2021_VSPW_Implement.
+ *
+ * The reference has no FFI on this path: its seam is a Python nn.Module surface whose every FLOP is an ATen op
+ * (SURVEY.md §8b).  Each entry point below therefore cites the reference call site(s) (file:line under
+ * /root/reference) whose ATen op it replaces.  INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every pointer is a DEVICE pointer to fp32 data unless stated otherwise;
+ *   - activations are NHWC: a tensor the reference calls [N,C,H,W] is stored as [N][H][W][C]
+ *     (torch memory_format=channels_last of the same logical shape); "rows" = N*H*W pixels;
+ *   - convolution weights are [Cout][KH][KW][Cin] (channels_last of the reference's OIHW parameter);
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered, nothing allocates or synchronises;
+ *   - every function returns VSPW_OK (0) or a negative error code and never throws;
+ *   - *_workspace() functions return the scratch bytes the matching call needs (caller allocates).
+ */
+#ifndef VSPW_HIP_H
+#define VSPW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSPW_OK 0
+#define VSPW_EINVAL (-1)  /* bad argument / geometry / workspace too small */
+#define VSPW_ELAUNCH (-2) /* hipLaunchKernel reported an error */
+
+#define VSPW_ABI_VERSION 1
+int vspw_abi_version(void);
+
+/* ---------------------------------------------------------------- convolution (conv_igemm.hip) ---- */
+/* Geometry of one nn.Conv2d call: x [n,h,w,c] -> y [n,oh,ow,k], square stride/pad/dilation.
+ * oh = (h + 2*pad - dil*(kh-1) - 1)/stride + 1 (checked). */
+typedef struct vspw_conv_desc {
+    int n, h, w, c;
+    int oh, ow, k;
+    int kh, kw, stride, pad, dil;
+} vspw_conv_desc;
+
+/* y = conv2d(x, w) (+ bias).  Replaces F.conv2d at models/resnet.py:61-66,100-106,130 (after the hyper-parameter
+ * rewrite of models/models.py:737-750), models/clip_psp.py:29,35,40,74,79, models/clip_ocr.py:43,56,58,62,
+ * models/ocr_modules/spatial_ocr_block.py:208-244,351, models/non_local.py:53-71, models/netwarp.py:41-54,97.
+ * stat_part (optional, may be NULL): [vspw_conv2d_stats_partials(d)][2][k] per-row-tile column sums of y and y*y,
+ * consumed by vspw_bn_reduce_partials_f32 (BatchNorm statistics fused into the conv epilogue). */
+int vspw_conv2d_fwd(const vspw_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                    float* stat_part, void* stream);
+size_t vspw_conv2d_stats_partials(const vspw_conv_desc* d);
+/* dx = conv2d_backward_input(dy, w).  wT is the [c][kh][kw][k] copy of w made by vspw_weight_transpose. */
+int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, const float* wT, float* dx, void* stream);
+/* dw [k][kh][kw][c] = conv2d_backward_weight(dy, x); split-K over pixels, deterministic reduction. */
+size_t vspw_conv2d_bwd_weight_workspace(const vspw_conv_desc* d);
+int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, const float* x, float* dw, void* ws,
+                           size_t ws_bytes, void* stream);
+/* [k][taps][c] -> [c][taps][k] */
+int vspw_weight_transpose(const float* w, float* wT, int k, int taps, int c, void* stream);
+/* [n][c][hw] -> [n][hw][c]: the reference feeds NCHW images (train_clip2.py:45-47). */
+int vspw_nchw_to_nhwc(const float* in, float* out, int n, int c, long long hw, void* stream);
+
+/* ---------------------------------------------------------------- batch norm (bn.hip) ------------- */
+/* Replaces SynchronizedBatchNorm2d.forward = F.batch_norm (models/sync_batchnorm/batchnorm.py:68-98) and its
+ * autograd backward, fused with the ReLU / residual add / Dropout2d that follow it in models/resnet.py:40-51,75-90,
+ * models/clip_psp.py:36-39,75-78 and models/clip_ocr.py:44-45,59-61. */
+size_t vspw_bn_stats_workspace(long long rows, int c);
+/* sums[0][c] = sum_rows x, sums[1][c] = sum_rows x*x, accumulated in fp64. */
+int vspw_bn_stats(const float* x, long long rows, int c, double* sums, void* ws, size_t ws_bytes, void* stream);
+/* Same sums from the per-tile fp32 partials written by vspw_conv2d_fwd(stat_part). */
+int vspw_bn_reduce_partials_f32(const float* part, int tiles, int c, double* sums, void* stream);
+/* Training-mode statistics -> per-channel coefficients.  count = number of rows behind `sums` (all ranks).
+ * mean, invstd = 1/sqrt(var_biased + eps); scale = gamma*invstd; shift = beta - mean*scale;
+ * running_mean/var updated with momentum and the unbiased variance (batchnorm.py:133-150); either may be NULL. */
+int vspw_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                     float* shift, int c, void* stream);
+/* Eval-mode coefficients from the running statistics. */
+int vspw_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, float* mean, float* invstd, float* scale, float* shift, int c, void* stream);
+/* z = [relu]( x*scale + shift [+ residual] ) [* chan_mask[image][c]]   (chan_mask = Dropout2d mask/(1-p)). */
+int vspw_bn_apply(const float* x, const float* scale, const float* shift, const float* residual,
+                  const float* chan_mask, float* z, long long rows, int c, long long rows_per_image, int relu,
+                  void* stream);
+size_t vspw_bn_bwd_workspace(long long rows, int c);
+/* g = dz * chan_mask * (relu ? z>0 : 1);  sums[0][c] = sum g, sums[1][c] = sum g*xhat, xhat=(x-mean)*invstd. */
+int vspw_bn_bwd_reduce(const float* dz, const float* z, const float* x, const float* mean, const float* invstd,
+                       const float* chan_mask, long long rows, int c, long long rows_per_image, int relu,
+                       double* sums, void* ws, size_t ws_bytes, void* stream);
+/* dx = gamma*invstd*(g - sums0/count - xhat*sums1/count) (training) or gamma*invstd*g (eval);
+ * dres = g (optional); dgamma = sums1, dbeta = sums0 (as fp32). */
+int vspw_bn_bwd_apply(const float* dz, const float* z, const float* x, const float* mean, const float* invstd,
+                      const float* gamma, const double* sums, double count, const float* chan_mask, long long rows,
+                      int c, long long rows_per_image, int relu, int training, float* dx, float* dres,
+                      float* dgamma, float* dbeta, void* stream);
+
+/* ---------------------------------------------------------------- pooling (pool.hip) -------------- */
+/* nn.MaxPool2d(3, stride 2, pad 1) of models/resnet.py:109; idx holds the winning tap (0..8) per output. */
+int vspw_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int n, int h, int w, int c, int oh, int ow,
+                          void* stream);
+int vspw_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int n, int h, int w, int c, int oh,
+                          int ow, void* stream);
+/* nn.AdaptiveAvgPool2d(s) (models/clip_psp.py:85-87,160-166, models/models.py:947,972): y [n][s][s][c]. */
+int vspw_adaptive_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int s, void* stream);
+/* dx (+)= adjoint; accumulate != 0 adds into dx. */
+int vspw_adaptive_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int s, int accumulate,
+                              void* stream);
+/* Temporal Context Blending of TCB-PSP (models/clip_psp.py:181-188): frames are stacked frame-major along the
+ * batch ([t][b]); y[b] = (1/T) sum_t x[t*B + b] * (wts ? wts[b*T + t] : 1). `inner` = elements per image. */
+int vspw_temporal_mean_fwd(const float* x, const float* wts, float* y, int T, int B, long long inner, void* stream);
+int vspw_temporal_mean_bwd(const float* dy, const float* wts, float* dx, int T, int B, long long inner,
+                           void* stream);
+
+/* ---------------------------------------------------------------- bilinear (interp.hip) ----------- */
+/* F.interpolate(mode='bilinear', align_corners=False) (models/clip_psp.py:49-52, models/models.py:96,102).
+ * Output rows have ldo channels and the result lands at channel offset co (writes straight into the PPM concat).
+ * The source rows have ldi channels, read at channel offset ci. */
+int vspw_bilinear_fwd(const float* x, float* y, int n, int ih, int iw, int oh, int ow, int c, int ldi, int ci,
+                      int ldo, int co, void* stream);
+int vspw_bilinear_bwd(const float* dy, float* dx, int n, int ih, int iw, int oh, int ow, int c, int ldi, int ci,
+                      int ldo, int co, void* stream);
+/* Strided channel-slice copy: dst[row][dco + j] = src[row][sco + j], j < c (torch.cat along channels). */
+int vspw_copy_channels(const float* src, float* dst, long long rows, int c, int lds, int sco, int ldd, int dco,
+                       void* stream);
+/* dst[row][j] += src[row][sco + j] */
+int vspw_add_channels(const float* src, float* dst, long long rows, int c, int lds, int sco, int ldd, int dco,
+                      void* stream);
+
+/* ---------------------------------------------------------------- softmax / loss (loss.hip) ------- */
+/* (log_)softmax over the contiguous last dimension (class channel of NHWC): F.log_softmax(dim=1) of
+ * models/clip_psp.py:198,212, softmax(dim=-1) of spatial_ocr_block.py:270.  y = softmax(alpha * x). */
+int vspw_softmax_lastdim_fwd(const float* x, float* y, long long rows, int k, float alpha, int log, void* stream);
+/* log: dx = dy - exp(y)*sum(dy);  prob: dx = alpha*y*(dy - sum(dy*y)) */
+int vspw_softmax_lastdim_bwd(const float* dy, const float* y, float* dx, long long rows, int k, float alpha, int log,
+                             void* stream);
+/* softmax over the pixel dimension of [b][hw][k] (spatial_ocr_block.py:104: F.softmax(probs, dim=2)). */
+int vspw_softmax_pixels_fwd(const float* x, float* y, int b, int hw, int k, float alpha, void* stream);
+int vspw_softmax_pixels_bwd(const float* dy, const float* y, float* dx, int b, int hw, int k, float alpha,
+                            void* stream);
+/* Fused  F.interpolate(logp,(H,W),bilinear) -> NLLLoss(ignore_index) -> pixel_acc  of models/clip_psp.py:198-216,
+ * models/models.py:92-107.  logp [n][h][w][k] are log-probabilities at feature resolution; label [n][H][W] int64.
+ * out[0]=sum of -logp_up[label] over non-ignored pixels, out[1]=#non-ignored, out[2]=#(argmax==label), out[3]=#(label>=0)
+ * (fp64).  out must be zeroed by the caller (vspw_zero_f64). */
+int vspw_seg_nll_fwd(const float* logp, const int64_t* label, double* out, int n, int h, int w, int k, int H, int W,
+                     int ignore_index, int want_acc, void* stream);
+/* Gathers the bilinear adjoint of -gscale/count at the label channel into d(loss)/d(logp) [n][h][w][k]; with
+ * lsm_jacobian != 0 it also applies the log-softmax Jacobian, i.e. returns d(loss)/d(logits) for
+ * logp = log_softmax(logits).  gscale is a device scalar (the incoming gradient of the loss). */
+int vspw_seg_nll_bwd(const float* logp, const int64_t* label, const double* fwd_out, const float* gscale,
+                     float* dlogits, int n, int h, int w, int k, int H, int W, int ignore_index, int lsm_jacobian,
+                     void* stream);
+/* Inference head: probs[n][H][W][k] = softmax_k(bilinear(logits)) (models/clip_psp.py:190-194). */
+int vspw_upsample_softmax(const float* logits, float* probs, int n, int h, int w, int k, int H, int W,
+                          void* stream);
+int vspw_zero_f64(double* p, long long n, void* stream);
+
+/* ---------------------------------------------------------------- misc (misc.hip) ----------------- */
+/* [b][r][c] -> [b][c][r] */
+int vspw_transpose_batched(const float* in, float* out, int b, int r, int c, void* stream);
+/* colsum[c] = sum_rows a[row][c]  (bias gradients) */
+size_t vspw_colsum_workspace(long long rows, int c);
+int vspw_colsum(const float* a, float* out, long long rows, int c, void* ws, size_t ws_bytes, void* stream);
+/* out[c] = sum_rows a[row][c]*b[row][c]  (gradients of per-channel blend weights) */
+int vspw_colsum_prod(const float* a, const float* b, float* out, long long rows, int c, void* ws, size_t ws_bytes,
+                     void* stream);
+/* y = a*x + b*y elementwise */
+int vspw_axpby(const float* x, float* y, long long n, float a, float b, void* stream);
+/* out = w0[c]*a + w1[c]*b per channel (NetWarp blend, models/netwarp.py:201,216-217) and its adjoints. */
+int vspw_chan_blend_fwd(const float* a, const float* b, const float* w0, const float* w1, float* out,
+                        long long rows, int c, void* stream);
+/* out[row][c] = w[c]*g[row][c] */
+int vspw_chan_scale(const float* g, const float* w, float* out, long long rows, int c, void* stream);
+/* flow-warp: grid_sample(bilinear, zeros, align_corners=False) with grid = 2*(xy+flow)/(dim-1)-1
+ * (models/netwarp.py:12-37).  x [n][h][w][c], flow [n][h][w][2] (dx,dy), y same shape as x. */
+int vspw_flowwarp_fwd(const float* x, const float* flow, float* y, int n, int h, int w, int c, void* stream);
+int vspw_flowwarp_bwd(const float* dy, const float* x, const float* flow, float* dx, float* dflow, int n, int h,
+                      int w, int c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VSPW_HIP_H */

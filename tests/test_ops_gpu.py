@@ -1,0 +1,372 @@
+"""Kernel-level parity: every HIP kernel (called through the C ABI via ops.py) against a plain PyTorch fp32 CPU
+evaluation of the ATen op it replaces, forward and backward, on seeded inputs incl. ragged / odd sizes.
+Tolerances: fp32 kernels with different summation order -> rtol 1e-4 / atol scaled to the reduction length."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol, what):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, tuple(a.shape), tuple(b.shape))
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item() + 1e-12
+    assert err <= tol * max(ref, 1.0), "%s: max abs err %.3e (ref max %.3e, tol %.1e)" % (what, err, ref, tol)
+
+
+CONV_CASES = [
+    # n, c, h, w, k, ks, stride, pad, dil, bias
+    (2, 64, 20, 27, 64, 3, 1, 2, 2, False),    # dil-2 (layer3 style), ragged M
+    (2, 32, 17, 19, 48, 3, 1, 4, 4, False),    # dil-4 (layer4 style), ragged N
+    (2, 64, 21, 23, 128, 3, 2, 1, 1, False),   # stride-2 3x3 (layer2.0.conv2)
+    (2, 64, 21, 23, 256, 1, 2, 0, 1, False),   # stride-2 1x1 downsample
+    (3, 256, 9, 13, 124, 1, 1, 0, 1, True),    # class head: Cout=124, bias
+    (2, 3, 33, 35, 64, 3, 2, 1, 1, False),     # stem conv1: Cin=3 scalar gather
+    (1, 11, 18, 22, 16, 3, 1, 1, 1, False),    # FlowCNN 11->16
+    (2, 4, 10, 12, 2, 3, 1, 1, 1, False),      # FlowCNN 4->2 (Cout=2)
+    (2, 512, 12, 12, 256, 3, 1, 1, 1, True),   # bigger K: 4608 reduction
+    (1, 124, 16, 16, 256, 1, 1, 0, 1, False),  # K=124 (not a multiple of 32)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(dev, case):
+    from cvpr2021_vspw_implement_amd import ops
+
+    n, c, h, w, k, ks, s, p, d, bias = case
+    g = torch.Generator().manual_seed(1234 + c + k)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(k, c, ks, ks, generator=g) * (2.0 / (c * ks * ks)) ** 0.5
+    b = torch.randn(k, generator=g) if bias else None
+    xr = x.clone().requires_grad_(True)
+    wr = wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride=s, padding=p, dilation=d)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+
+    xd = x.to(dev).requires_grad_(True)
+    wd = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True) if bias else None
+    yd = ops.conv2d(xd, wd, bd, s, p, d)
+    yd.backward(gy.to(dev))
+    red = c * ks * ks
+    _close(yd, yr, 2e-6 * red ** 0.5 + 1e-5, "conv fwd %s" % (case,))
+    _close(xd.grad, xr.grad, 2e-6 * (k * ks * ks) ** 0.5 + 1e-5, "conv dgrad %s" % (case,))
+    _close(wd.grad, wr.grad, 3e-6 * (n * yr.shape[2] * yr.shape[3]) ** 0.5 + 1e-5, "conv wgrad %s" % (case,))
+    if bias:
+        _close(bd.grad, br.grad, 1e-5, "conv bias grad %s" % (case,))
+
+
+@pytest.mark.parametrize("shape,relu,res,train", [
+    ((4, 64, 9, 11), True, False, True),
+    ((2, 256, 7, 5), True, True, True),
+    ((2, 6, 5, 5), False, False, True),      # C not multiple of 4
+    ((3, 128, 6, 6), True, True, False),     # eval-mode statistics
+    ((2, 256, 124, 1), True, False, True),   # OCR proxy shape
+])
+def test_batchnorm_act(dev, shape, relu, res, train):
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(7)
+    n, c, h, w = shape
+    x = torch.randn(shape, generator=g) * 2 + 0.5
+    r = torch.randn(shape, generator=g) if res else None
+    gamma = torch.rand(c, generator=g) + 0.5
+    beta = torch.randn(c, generator=g)
+    rm = torch.randn(c, generator=g) * 0.1
+    rv = torch.rand(c, generator=g) + 0.5
+    gy = torch.randn(shape, generator=g)
+
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    y = F.batch_norm(xr, rm_r, rv_r, gr, br, train, 0.1, 1e-5)
+    if res:
+        y = y + rr
+    if relu:
+        y = F.relu(y)
+    y.backward(gy)
+
+    xd = x.to(dev).requires_grad_(True)
+    rd = r.to(dev).requires_grad_(True) if res else None
+    gd = gamma.to(dev).requires_grad_(True)
+    bd = beta.to(dev).requires_grad_(True)
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    yd = ops.batch_norm_act(xd, gd, bd, rm_d, rv_d, rd, None, train, 0.1, 1e-5, relu)
+    yd.backward(gy.to(dev))
+    _close(yd, y, 2e-5, "bn fwd")
+    _close(xd.grad, xr.grad, 5e-5, "bn dx")
+    _close(gd.grad, gr.grad, 5e-5, "bn dgamma")
+    _close(bd.grad, br.grad, 5e-5, "bn dbeta")
+    if res:
+        _close(rd.grad, rr.grad, 1e-6, "bn dres")
+    _close(rm_d, rm_r, 1e-5, "running_mean")
+    _close(rv_d, rv_r, 1e-5, "running_var")
+
+
+def test_conv_bn_act_fused_and_dropout(dev):
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    n, c, h, w, k = 3, 64, 13, 15, 96
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(k, c, 3, 3, generator=g) * 0.05
+    cb = torch.randn(k, generator=g)
+    gamma = torch.rand(k, generator=g) + 0.5
+    beta = torch.randn(k, generator=g)
+    res = torch.randn(n, k, h, w, generator=g)
+    mask = (torch.rand(n, k, generator=g) < 0.8).float() / 0.8
+    gy = torch.randn(n, k, h, w, generator=g)
+
+    leaves = [t.clone().requires_grad_(True) for t in (x, wt, cb, gamma, beta, res)]
+    xr, wr, cbr, gr, br, rr = leaves
+    rm, rv = torch.zeros(k), torch.ones(k)
+    y = F.conv2d(xr, wr, cbr, padding=2, dilation=2)
+    y = F.relu(F.batch_norm(y, rm, rv, gr, br, True, 0.1, 1e-5) + rr) * mask[:, :, None, None]
+    y.backward(gy)
+
+    dl = [t.to(dev).requires_grad_(True) for t in (x, wt.contiguous(memory_format=torch.channels_last), cb, gamma,
+                                                   beta, res)]
+    xd, wd, cbd, gd, bd, rd = dl
+    rmd, rvd = torch.zeros(k, device=dev), torch.ones(k, device=dev)
+    yd = ops.conv_bn_act(xd, wd, cbd, gd, bd, rmd, rvd, rd, mask.to(dev), 1, 2, 2, True, 0.1, 1e-5, True)
+    yd.backward(gy.to(dev))
+    _close(yd, y, 1e-4, "fused fwd")
+    for a, b, nm in zip(dl, leaves, ("dx", "dw", "dcbias", "dgamma", "dbeta", "dres")):
+        _close(a.grad, b.grad, 3e-4, "fused " + nm)
+    _close(rmd, rm, 1e-5, "fused running_mean")
+    _close(rvd, rv, 1e-5, "fused running_var")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 33, 35), (1, 128, 240, 240), (2, 64, 16, 17)])
+def test_maxpool(dev, shape):
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    x = F.relu(torch.randn(shape, generator=g))  # many exact-zero ties, like post-ReLU activations
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool2d(xr, 3, 2, 1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = x.to(dev).requires_grad_(True)
+    yd = ops.max_pool3x3s2(xd)
+    yd.backward(gy.to(dev))
+    _close(yd, y, 0.0, "maxpool fwd")
+    _close(xd.grad, xr.grad, 1e-6, "maxpool bwd")
+
+
+@pytest.mark.parametrize("hw,T", [((60, 60), 1), ((60, 107), 1), ((9, 13), 3), ((8, 12), 5)])
+def test_pyramid_pool_temporal_mean(dev, hw, T):
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    B, c = 2, 32
+    h, w = hw
+    x = torch.randn(T * B, c, h, w, generator=g)
+    scales = (1, 2, 3, 6)
+    xr = x.clone().requires_grad_(True)
+    outs_r = []
+    for s in scales:
+        p = F.adaptive_avg_pool2d(xr, s)
+        chunks = torch.split(p, B, dim=0)
+        feats = [chunks[-1].unsqueeze(-1)] + [ch.unsqueeze(-1) for ch in chunks[:-1]]
+        outs_r.append(torch.mean(torch.cat(feats, -1), -1))
+    gys = [torch.randn(o.shape, generator=g) for o in outs_r]
+    torch.autograd.backward(outs_r, gys)
+    xd = x.to(dev).requires_grad_(True)
+    outs_d = ops.pyramid_pool(xd, scales, T, None)
+    torch.autograd.backward(list(outs_d), [gy.to(dev) for gy in gys])
+    for a, b, s in zip(outs_d, outs_r, scales):
+        _close(a, b, 1e-5, "pool scale %d" % s)
+    _close(xd.grad, xr.grad, 1e-5, "pool bwd")
+
+
+@pytest.mark.parametrize("ih,iw,oh,ow", [(6, 6, 60, 107), (1, 1, 9, 13), (60, 107, 480, 853), (3, 3, 8, 12), (2, 2, 60, 60)])
+def test_bilinear_and_ppm_concat(dev, ih, iw, oh, ow):
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    n, c = 2, 8
+    if oh * ow > 100000:
+        n, c = 1, 4
+    x = torch.randn(n, c, ih, iw, generator=g)
+    xr = x.clone().requires_grad_(True)
+    y = F.interpolate(xr, (oh, ow), mode="bilinear", align_corners=False)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd = x.to(dev).requires_grad_(True)
+    yd = ops.interpolate_bilinear(xd, (oh, ow))
+    yd.backward(gy.to(dev))
+    _close(yd, y, 1e-5, "bilinear fwd")
+    _close(xd.grad, xr.grad, 1e-4, "bilinear bwd")
+
+
+def test_ppm_concat(dev):
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(10)
+    n, c, h, w = 2, 16, 12, 17
+    x = torch.randn(n, c, h, w, generator=g)
+    brs = [torch.randn(n, 8, s, s, generator=g) for s in (1, 2, 3, 6)]
+    leaves = [t.clone().requires_grad_(True) for t in [x] + brs]
+    y = torch.cat([leaves[0]] + [F.interpolate(b, (h, w), mode="bilinear", align_corners=False) for b in leaves[1:]], 1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    dl = [t.to(dev).requires_grad_(True) for t in [x] + brs]
+    yd = ops.ppm_concat(dl[0], dl[1:])
+    yd.backward(gy.to(dev))
+    _close(yd, y, 1e-5, "ppm concat fwd")
+    for a, b in zip(dl, leaves):
+        _close(a.grad, b.grad, 1e-4, "ppm concat bwd")
+
+
+@pytest.mark.parametrize("hw,HW,k", [((8, 8), (65, 65), 124), ((60, 60), (479, 479), 124), ((8, 12), (64, 96), 7)])
+def test_seg_nll(dev, hw, HW, k):
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(21)
+    n = 2
+    h, w = hw
+    H, W = HW
+    logits = torch.randn(n, k, h, w, generator=g) * 3
+    label = torch.randint(0, k, (n, 1, H, W), generator=g).float()
+    label[torch.rand(n, 1, H, W, generator=g) < 0.05] = 255.0
+    lr = logits.clone().requires_grad_(True)
+    pred = F.interpolate(F.log_softmax(lr, dim=1), (H, W), mode="bilinear", align_corners=False)
+    lab = label.squeeze(1).long()
+    loss_r = F.nll_loss(pred, lab, ignore_index=255)
+    preds = pred.argmax(1)
+    acc_r = ((preds == lab) & (lab >= 0)).sum().float() / ((lab >= 0).sum().float() + 1e-10)
+    (loss_r * 1.7).backward()
+    ld = logits.to(dev).requires_grad_(True)
+    loss_d, acc_d = ops.seg_nll(ld, label.to(dev), 255, True, True)
+    (loss_d * 1.7).backward()
+    _close(loss_d, loss_r, 1e-5, "nll loss")
+    assert abs(acc_d.item() - acc_r.item()) < 2e-4, (acc_d.item(), acc_r.item())
+    _close(ld.grad, lr.grad, 2e-5, "nll dlogits")
+    # log-prob input variant (per-frame SegmentationModule path)
+    lp = F.log_softmax(logits, dim=1)
+    lpr = lp.clone().requires_grad_(True)
+    F.nll_loss(F.interpolate(lpr, (H, W), mode="bilinear", align_corners=False), lab, ignore_index=255).backward()
+    lpd = lp.to(dev).requires_grad_(True)
+    l2, _ = ops.seg_nll(lpd, label.to(dev), 255, False, False)
+    l2.backward()
+    _close(l2, loss_r, 1e-5, "nll loss (logp)")
+    _close(lpd.grad, lpr.grad, 2e-5, "nll dlogp")
+
+
+def test_softmaxes_and_upsample_softmax(dev):
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 124, 9, 13, generator=g) * 4
+    for log in (True, False):
+        xr = x.clone().requires_grad_(True)
+        y = F.log_softmax(xr, 1) if log else F.softmax(xr, 1)
+        gy = torch.randn(y.shape, generator=g)
+        y.backward(gy)
+        xd = x.to(dev).requires_grad_(True)
+        yd = ops.log_softmax_channels(xd) if log else ops.softmax_channels(xd)
+        yd.backward(gy.to(dev))
+        _close(yd, y, 1e-5, "softmax fwd log=%s" % log)
+        _close(xd.grad, xr.grad, 1e-5, "softmax bwd log=%s" % log)
+    a = torch.randn(2, 117, 124, generator=g)
+    ar = a.clone().requires_grad_(True)
+    y = F.softmax(0.0625 * ar, -1)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    ad = a.to(dev).requires_grad_(True)
+    yd = ops.row_softmax(ad, 0.0625)
+    yd.backward(gy.to(dev))
+    _close(yd, y, 1e-6, "row softmax")
+    _close(ad.grad, ar.grad, 1e-6, "row softmax bwd")
+    ar = a.clone().requires_grad_(True)
+    y = F.softmax(ar, 1)
+    y.backward(gy)
+    ad = a.to(dev).requires_grad_(True)
+    yd = ops.pixel_softmax(ad, 1.0)
+    yd.backward(gy.to(dev))
+    _close(yd, y, 1e-6, "pixel softmax")
+    _close(ad.grad, ar.grad, 1e-6, "pixel softmax bwd")
+    logits = torch.randn(1, 124, 8, 12, generator=g) * 3
+    pr = F.softmax(F.interpolate(logits, (64, 96), mode="bilinear", align_corners=False), 1)
+    pd = ops.upsample_softmax(logits.to(dev), (64, 96))
+    _close(pd, pr, 1e-5, "upsample softmax")
+    assert (pd.argmax(1).cpu() == pr.argmax(1)).float().mean().item() > 0.999
+
+
+def test_bmm_and_transpose(dev):
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(41)
+    a = torch.randn(2, 117, 64, generator=g)
+    bt = torch.randn(2, 124, 64, generator=g)
+    ar, br = a.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    y = ar @ br.transpose(1, 2)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    ad, bd = a.to(dev).requires_grad_(True), bt.to(dev).requires_grad_(True)
+    yd = ops.bmm_nt(ad, bd)
+    yd.backward(gy.to(dev))
+    _close(yd, y, 2e-5, "bmm_nt")
+    _close(ad.grad, ar.grad, 2e-5, "bmm_nt da")
+    _close(bd.grad, br.grad, 2e-5, "bmm_nt db")
+    p = torch.randn(2, 117, 124, generator=g)
+    f = torch.randn(2, 117, 32, generator=g)
+    pr, fr = p.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    y = pr.transpose(1, 2) @ fr
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    pd, fd = p.to(dev).requires_grad_(True), f.to(dev).requires_grad_(True)
+    yd = ops.bmm_tn(pd, fd)
+    yd.backward(gy.to(dev))
+    _close(yd, y, 2e-5, "bmm_tn")
+    _close(pd.grad, pr.grad, 2e-5, "bmm_tn da")
+    _close(fd.grad, fr.grad, 2e-5, "bmm_tn db")
+    _close(ops.transpose_last2(a.to(dev)), a.transpose(1, 2).contiguous(), 0.0, "transpose")
+
+
+def test_flowwarp_and_blend(dev):
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(51)
+    B, C, H, W = 2, 40, 15, 19
+    x = torch.randn(B, C, H, W, generator=g)
+    flo = (torch.randn(B, 2, H, W, generator=g) * 1.9 - 0.7).clamp(-10, 10)
+    flo[0, :, 0, 0] = torch.tensor([-30.0, 25.0])  # out-of-bounds taps
+
+    def ref_warp(x, flo):
+        xx = torch.arange(0, W).view(1, -1).repeat(H, 1).view(1, 1, H, W).repeat(B, 1, 1, 1)
+        yy = torch.arange(0, H).view(-1, 1).repeat(1, W).view(1, 1, H, W).repeat(B, 1, 1, 1)
+        vgrid = torch.cat((xx, yy), 1).float() + flo
+        vx = 2.0 * vgrid[:, 0] / max(W - 1, 1) - 1.0
+        vy = 2.0 * vgrid[:, 1] / max(H - 1, 1) - 1.0
+        return F.grid_sample(x, torch.stack((vx, vy), -1), align_corners=False)
+
+    xr, fr = x.clone().requires_grad_(True), flo.clone().requires_grad_(True)
+    y = ref_warp(xr, fr)
+    gy = torch.randn(y.shape, generator=g)
+    y.backward(gy)
+    xd, fd = x.to(dev).requires_grad_(True), flo.to(dev).requires_grad_(True)
+    yd = ops.flowwarp(xd, fd)
+    yd.backward(gy.to(dev))
+    _close(yd, y, 1e-5, "flowwarp fwd")
+    _close(xd.grad, xr.grad, 1e-5, "flowwarp dx")
+    _close(fd.grad, fr.grad, 1e-4, "flowwarp dflow")
+    w0, w1 = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    b = torch.randn(B, C, H, W, generator=g)
+    leaves = [t.clone().requires_grad_(True) for t in (x, b, w0, w1)]
+    out = leaves[2].view(1, -1, 1, 1) * leaves[0] + leaves[3].view(1, -1, 1, 1) * leaves[1]
+    out.backward(gy)
+    dl = [t.to(dev).requires_grad_(True) for t in (x, b, w0, w1)]
+    od = ops.chan_blend(*dl)
+    od.backward(gy.to(dev))
+    _close(od, out, 1e-6, "blend fwd")
+    for a, r in zip(dl, leaves):
+        _close(a.grad, r.grad, 2e-5, "blend bwd")

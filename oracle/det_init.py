@@ -1,0 +1,56 @@
+"""ORACLE / test infrastructure: deterministic, name-keyed parameter values.
+
+The golden fixtures were produced by loading exactly these values into the REFERENCE modules
+(tools/make_golden.py); the GPU tests load the same values into the HIP-backed modules, and the numpy oracle reads
+them directly — so no weights need to be stored or shipped.  numpy's legacy RandomState stream is stable across
+versions; values depend only on (state_dict key, shape, seed).
+"""
+import zlib
+
+import numpy as np
+
+
+# final classifier convolutions: small weights so that logits are O(1) like a trained network's
+_CLASSIFIERS = ("conv_last_.4.weight", "conv_last.4.weight", "deepsup.4.weight", "dsn_head.4.weight", "head.weight",
+                "last_layer.weight", "conv_last_deepsup_.weight")
+
+
+def det_tensor(name, shape, seed=304):
+    rs = np.random.RandomState((zlib.crc32(name.encode()) + seed * 7919) & 0x7FFFFFFF)
+    shape = tuple(int(s) for s in shape)
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "num_batches_tracked":
+        return np.zeros(shape, dtype=np.int64)
+    if leaf == "running_mean":
+        return (rs.randn(*shape) * 0.1).astype(np.float32)
+    if leaf == "running_var":
+        return rs.uniform(0.5, 1.5, size=shape).astype(np.float32)
+    if len(shape) >= 2:  # conv / linear weights: He-normal on fan-in
+        fan_in = int(np.prod(shape[1:]))
+        gain = 0.25 if name.endswith(_CLASSIFIERS) else 1.0
+        return (rs.randn(*shape) * (gain * np.sqrt(2.0 / fan_in))).astype(np.float32)
+    if leaf == "weight":  # BatchNorm gamma (and NetWarp blend vectors end in w*_* -> handled below)
+        return rs.uniform(0.5, 1.5, size=shape).astype(np.float32)
+    if leaf == "bias":
+        return (rs.randn(*shape) * 0.1).astype(np.float32)
+    return rs.uniform(0.2, 0.8, size=shape).astype(np.float32)  # w0_0 ... w1_1 blend vectors
+
+
+def det_state_dict(keys_and_shapes, seed=304):
+    return {k: det_tensor(k, s, seed) for k, s in keys_and_shapes}
+
+
+def det_input(tag, shape, seed=304, scale=1.0):
+    rs = np.random.RandomState((zlib.crc32(("input:" + tag).encode()) + seed * 7919) & 0x7FFFFFFF)
+    return (rs.randn(*shape) * scale).astype(np.float32)
+
+
+def det_labels(tag, shape, num_class, seed=304, ignore_frac=0.05):
+    """Piecewise-constant label maps (8x8 blocks) with ~5% ignore (255), as float32 like the reference's loader
+    hands them over (dataset2.py:970-977)."""
+    rs = np.random.RandomState((zlib.crc32(("label:" + tag).encode()) + seed * 7919) & 0x7FFFFFFF)
+    n, _, h, w = shape
+    coarse = rs.randint(0, num_class, size=(n, 1, (h + 7) // 8, (w + 7) // 8))
+    lab = np.repeat(np.repeat(coarse, 8, 2), 8, 3)[:, :, :h, :w].astype(np.float32)
+    lab[rs.rand(n, 1, h, w) < ignore_frac] = 255.0
+    return lab

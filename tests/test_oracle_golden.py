@@ -1,0 +1,133 @@
+"""Pins the numpy oracle (oracle/) against golden vectors generated from the reference itself
+(tools/make_golden.py).  Two levels:
+  * float64: the oracle re-run in double must agree with the reference re-run in double to ~1e-7 — this pins the
+    restated SEMANTICS (bin edges, biased/unbiased variance, tap weights, reduction sets ...) free of rounding noise;
+  * float32: the oracle in the reference's arithmetic type must agree within fp32 rounding-noise tolerances.
+CPU only."""
+import numpy as np
+import pytest
+
+from oracle import np_models as NM
+from oracle import np_ops as O
+from oracle.det_init import det_input, det_labels
+from oracle.np_ops import Var
+
+from helpers import (build, check_argmax, check_grad_norms, clip_inputs, det_numpy_state, golden, logit_tol,
+                     seg_inputs)
+
+
+@pytest.fixture(autouse=True)
+def _fp32_by_default():
+    O.set_dtype(np.float32)
+    yield
+    O.set_dtype(np.float32)
+
+
+def test_op_vectors_from_reference():
+    fx = golden("ops_reference")
+    x = det_input("ops_reference:warp_x", (2, 6, 9, 11))
+    y = O.flowwarp(Var(x), Var(fx["flowwarp_flow"]))
+    assert np.abs(y.v - fx["flowwarp"]).max() < 1e-5
+    feats = det_input("ops_reference:g_feats", (2, 32, 9, 13))
+    probs = det_input("ops_reference:g_probs", (2, 7, 9, 13), scale=2.0)
+    ctx = NM._gather(Var(feats), Var(probs))
+    assert ctx.shape == fx["ocr_gather"].shape
+    assert np.abs(ctx.v - fx["ocr_gather"]).max() < 1e-5
+    pa_pred = det_input("ops_reference:pa", (2, 5, 6, 7))
+    pa_lab = det_labels("ops_reference:pa", (2, 1, 6, 7), 5)
+    assert abs(O.pixel_acc(pa_pred, pa_lab) - float(fx["pixel_acc"])) < 1e-7
+
+
+def _scalar(v):
+    return float(np.asarray(v.v).reshape(()))
+
+
+def _grad_norm_err64(P, fx):
+    names = [str(n) for n in fx["grad_names"]]
+    ref = fx["grad_norms64"]
+    g = P.grads()
+    scale = ref.max()
+    return max(abs(np.linalg.norm(g[n]) - r) / max(r, 1e-6 * scale) for n, r in zip(names, ref))
+
+
+def _run_seg(fx, sd, arch, decoder, inp, training, dss):
+    P = NM.Params({k: v.copy() for k, v in sd.items()}, train_params=training)
+    base = arch.replace("dilated", "")
+    if training:
+        loss, acc = NM.segmentation_module(P, base, inp["train_img"], inp["train_lab"], True, deep_sup_scale=dss,
+                                           decoder=decoder)
+        return P, loss, acc
+    return P, NM.segmentation_module(P, base, inp["eval_img"], None, False, seg_size=(64, 96), decoder=decoder), None
+
+
+@pytest.mark.parametrize("tag,arch,decoder,fc_dim", [
+    ("r18_ppm_deepsup", "resnet18dilated", "ppm_deepsup", 512),
+    ("r50_ocrnet_deepsup", "resnet50dilated", "ocrnet_deepsup", 2048),
+    ("r50_nonlocal2d", "resnet50dilated", "nonlocal2d", 2048),
+])
+def test_per_frame_models_match_reference(tag, arch, decoder, fc_dim):
+    fx = golden(tag)
+    dss = None if decoder == "nonlocal2d" else 0.4
+    mod = build("seg", arch, decoder, fc_dim, deep_sup_scale=dss)
+    sd = det_numpy_state(mod, fx=fx)
+    NM._flat_w(sd, list(sd))
+    inp = seg_inputs(tag)
+    # ---- float64: semantics
+    O.set_dtype(np.float64)
+    P, loss, _ = _run_seg(fx, sd, arch, decoder, inp, True, dss)
+    assert abs(_scalar(loss) - float(fx["train_loss64"])) < 1e-9 * abs(float(fx["train_loss64"])) + 1e-10
+    O.tape().backward(loss)
+    assert _grad_norm_err64(P, fx) < 1e-6
+    # ---- float32: the reference's arithmetic type
+    O.set_dtype(np.float32)
+    P, probs, _ = _run_seg(fx, sd, arch, decoder, inp, False, dss)
+    tol = logit_tol(fx)
+    assert np.abs(probs.v[:, :, ::4, ::4] - fx["eval_probs_sub"]).max() < tol
+    check_argmax(probs.v.argmax(1), fx, tol)
+    P, loss, acc = _run_seg(fx, sd, arch, decoder, inp, True, dss)
+    assert abs(_scalar(loss) - float(fx["train_loss"])) < 2e-4 * abs(float(fx["train_loss"]))
+    assert abs(acc - float(fx["train_acc"])) < 2e-3
+    O.tape().backward(loss)
+    check_grad_norms(P.grads(), fx, 3e-2, tag)
+    for key in fx.files:
+        if key.startswith("grad:"):
+            g, ref = P.grads()[key[5:]], fx[key]
+            # fp32 gradients through ~50 train-mode BN layers on an 9x9 map are noisy (ReLU / max-pool decisions
+            # flip under rounding); the tight pin is the float64 block above
+            assert np.linalg.norm(g - ref) <= 0.1 * np.linalg.norm(ref), key
+    assert np.abs(P.sd["encoder.bn1.running_mean"] - fx["bn_running_mean:encoder.bn1"]).max() < 1e-5
+    assert np.abs(P.sd["encoder.bn1.running_var"] - fx["bn_running_var:encoder.bn1"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["clip_psp", "clip_ocr"])
+def test_clip_heads_match_reference(kind):
+    tag = "r50_" + kind
+    fx = golden(tag)
+    mod = build(kind, "resnet50dilated")
+    sd = det_numpy_state(mod, fx=fx)
+    inp = clip_inputs(tag)
+    fn = {"clip_psp": NM.clip_psp, "clip_ocr": NM.clip_ocr}[kind]
+    # ---- float64
+    O.set_dtype(np.float64)
+    P = NM.Params({k: v.copy() for k, v in sd.items()}, train_params=False)
+    _, logits = fn(P, "resnet50", inp["eval_imgs"], None, False, seg_size=(64, 96))
+    assert np.abs(logits.v - fx["eval_logits64"]).max() < 1e-8
+    P = NM.Params({k: v.copy() for k, v in sd.items()}, train_params=True)
+    loss, _ = fn(P, "resnet50", inp["train_imgs"], inp["train_labs"], True)
+    assert abs(_scalar(loss) - float(fx["train_loss64"])) < 1e-9 * abs(float(fx["train_loss64"])) + 1e-10
+    O.tape().backward(loss)
+    assert _grad_norm_err64(P, fx) < 1e-6
+    # ---- float32
+    O.set_dtype(np.float32)
+    P = NM.Params({k: v.copy() for k, v in sd.items()}, train_params=False)
+    probs, logits = fn(P, "resnet50", inp["eval_imgs"], None, False, seg_size=(64, 96))
+    tol = logit_tol(fx)
+    assert np.abs(logits.v - fx["eval_logits"]).max() < tol
+    assert np.abs(probs.v[:, :, ::4, ::4] - fx["eval_probs_sub"]).max() < tol
+    check_argmax(probs.v.argmax(1), fx, tol)
+    P = NM.Params({k: v.copy() for k, v in sd.items()}, train_params=True)
+    loss, acc = fn(P, "resnet50", inp["train_imgs"], inp["train_labs"], True)
+    assert abs(_scalar(loss) - float(fx["train_loss"])) < 2e-4 * abs(float(fx["train_loss"]))
+    assert abs(acc - float(fx["train_acc"])) < 2e-3
+    O.tape().backward(loss)
+    check_grad_norms(P.grads(), fx, 3e-2, tag)

@@ -1,0 +1,352 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported read-only from /root/reference) on small,
+seeded cases.  Runs only in the build container (the GPU box has no /root/reference); the fixtures it writes contain
+arrays only: inputs are regenerated from seeds (oracle/det_init.py), weights likewise, so a fixture holds the expected
+outputs (logits, probabilities, arg-max, loss, accuracy, gradients / gradient norms).
+
+    python tools/make_golden.py            # (re)writes every fixture
+
+Nothing from the reference is copied: it is imported, executed and discarded.
+"""
+import os
+import sys
+import types
+
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from oracle.det_init import det_input, det_labels, det_tensor  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+K = 124
+
+
+def import_reference():
+    sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+    sys.path.insert(0, REF)
+    sys.path.insert(0, os.path.join(REF, "RAFT_core"))
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import models as ref_models  # noqa
+    finally:
+        os.chdir(cwd)
+    return ref_models
+
+
+def load_det(module, seed=304):
+    sd = module.state_dict()
+    new = {k: torch.from_numpy(det_tensor(k, v.shape, seed)).to(v.dtype) for k, v in sd.items()}
+    module.load_state_dict(new, strict=True)
+
+
+def calibrate_bn(module, run_train_forward):
+    """Make eval-mode BatchNorm meaningful for random weights: one training-mode forward with momentum 1 sets every
+    running statistic to the batch statistic of the calibration input.  Returns them for storage in the fixture."""
+    bns = [m for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    for m in bns:
+        m.momentum = 1.0
+    module.train()
+    with torch.no_grad():
+        run_train_forward()
+    for m in bns:
+        m.momentum = 0.1
+    return {"bnstat:" + k: v.numpy().copy() for k, v in module.state_dict().items()
+            if k.endswith("running_mean") or k.endswith("running_var")}
+
+
+def double_pass(module, reload_sd, run_train, hook_mod=None, run_eval=None):
+    """Same case in float64 (reference cast with .double()): pins semantics free of fp32 rounding noise."""
+    module.double()
+    module.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in reload_sd.items()}, strict=False)
+    out = {}
+    if run_eval is not None:
+        module.eval()
+        store = {}
+        h = hook_output(hook_mod, store, "logits")
+        with torch.no_grad():
+            run_eval()
+        h.remove()
+        out["eval_logits64"] = store["logits"].numpy().copy()
+    module.train()
+    module.zero_grad()
+    loss, acc = run_train()
+    loss.backward()
+    out["train_loss64"] = np.float64(loss.item())
+    names, norms = [], []
+    for k, p in module.named_parameters():
+        if p.grad is not None:
+            names.append(k)
+            norms.append(float(p.grad.norm()))
+    out["grad_norms64"] = np.array(norms, dtype=np.float64)
+    module.float()
+    return out
+
+
+def zero_dropout(module):
+    for m in module.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+
+
+def grads_summary(module, full=()):
+    out = {}
+    names, norms = [], []
+    for k, p in module.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+        if k in full:
+            out["grad:" + k] = p.grad.detach().numpy().copy()
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms, dtype=np.float64)
+    return out
+
+
+def top2_margin(probs):
+    """log p(top1) - log p(top2) = gap between the two largest up-sampled LOGITS (softmax is monotone)."""
+    s = np.sort(probs.astype(np.float64), axis=1)
+    return (np.log(s[:, -1]) - np.log(np.maximum(s[:, -2], 1e-300))).astype(np.float32)
+
+
+def eval_pack(probs, logits):
+    probs = probs.detach().numpy()
+    out = {"probs_sub": probs[:, :, ::4, ::4].copy(), "argmax": probs.argmax(1).astype(np.uint8),
+           "margin": top2_margin(probs)}
+    if logits is not None:
+        out["logits"] = logits.detach().numpy().copy()
+    return out
+
+
+def hook_output(mod, store, key):
+    return mod.register_forward_hook(lambda m, i, o: store.__setitem__(key, o.detach().clone()))
+
+
+def args_ns(**kw):
+    base = dict(num_class=K, psp_weight=False, use_memory=False, memory_num=0, clipocr_all=False, clip_num=3)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def case_segmodule(M, arch, decoder, tag, train_shape=(2, 3, 65, 65), eval_shape=(1, 3, 64, 96), fc_dim=512):
+    torch.manual_seed(0)
+    enc = M.ModelBuilder.build_encoder(arch=arch, fc_dim=fc_dim)
+    dec = M.ModelBuilder.build_decoder(arch=decoder, fc_dim=fc_dim, num_class=K)
+    crit = torch.nn.NLLLoss(ignore_index=255)
+    mod = M.SegmentationModule(enc, dec, crit, 0.4 if decoder != "nonlocal2d" else None)
+    load_det(mod)
+    zero_dropout(mod)
+    res = {}
+    cal_img = torch.from_numpy(det_input(tag + ":train", train_shape))
+    cal_lab = torch.from_numpy(det_labels(tag + ":train", (train_shape[0], 1) + train_shape[2:], K))
+    res.update(calibrate_bn(mod, lambda: mod({"img_data": cal_img, "seg_label": cal_lab})))
+    calibrated_sd = {k: v.clone() for k, v in mod.state_dict().items()}
+    # eval
+    mod.eval()
+    store = {}
+    last = {"ppm_deepsup": "conv_last_", "ocrnet_deepsup": "head", "nonlocal2d": "last_layer"}[decoder]
+    h = hook_output(getattr(mod.decoder, last), store, "logits")
+    img = torch.from_numpy(det_input(tag + ":eval", eval_shape))
+    with torch.no_grad():
+        probs = mod({"img_data": img, "seg_label": torch.zeros(eval_shape[0], 1, *eval_shape[2:])},
+                    segSize=eval_shape[2:])
+    h.remove()
+    for k, v in eval_pack(probs, store["logits"]).items():
+        res["eval_" + k] = v
+    # train
+    mod.train()
+    img = torch.from_numpy(det_input(tag + ":train", train_shape))
+    lab = torch.from_numpy(det_labels(tag + ":train", (train_shape[0], 1) + train_shape[2:], K))
+    mod.zero_grad()
+    loss, acc = mod({"img_data": img, "seg_label": lab})
+    loss.backward()
+    res["train_loss"] = np.float64(loss.item())
+    res["train_acc"] = np.float64(acc.item())
+    res.update(grads_summary(mod, full=("encoder.conv1.weight", "encoder.layer1.0.conv2.weight",
+                                        "encoder.layer4.1.bn2.weight", "encoder.layer2.0.downsample.0.weight")))
+    res["bn_running_mean:encoder.bn1"] = mod.encoder.bn1.running_mean.numpy().copy()
+    res["bn_running_var:encoder.bn1"] = mod.encoder.bn1.running_var.numpy().copy()
+    eimg = torch.from_numpy(det_input(tag + ":eval", eval_shape)).double()
+    res.update(double_pass(
+        mod, calibrated_sd, lambda: mod({"img_data": img.double(), "seg_label": lab.double()}),
+        getattr(mod.decoder, last),
+        lambda: mod({"img_data": eimg, "seg_label": torch.zeros(eval_shape[0], 1, *eval_shape[2:])},
+                    segSize=eval_shape[2:])))
+    res["meta"] = np.array([arch, decoder, str(train_shape), str(eval_shape), str(fc_dim)])
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, "loss %.6f acc %.4f" % (loss.item(), acc.item()))
+
+
+def case_clip(M, method, arch, tag, T=3, train_shape=(2, 3, 65, 65), eval_shape=(1, 3, 64, 96)):
+    torch.manual_seed(0)
+    enc = M.ModelBuilder.build_encoder(arch=arch, fc_dim=2048)
+    crit = torch.nn.NLLLoss(ignore_index=255)
+    cls = {"clip_psp": M.Clip_PSP, "clip_ocr": M.ClipOCRNet}[method]
+    mod = cls(enc, crit, args_ns(), deep_sup_scale=0.4)
+    load_det(mod)
+    zero_dropout(mod)
+    res = {}
+    cimgs = [torch.from_numpy(det_input("%s:train:%d" % (tag, t), train_shape)) for t in range(T)]
+    clabs = [torch.from_numpy(det_labels("%s:train:%d" % (tag, t), (train_shape[0], 1) + train_shape[2:], K))
+             for t in range(T)]
+    res.update(calibrate_bn(mod, lambda: mod({"img_data": cimgs[-1], "seg_label": clabs[-1],
+                                              "clipimgs_data": list(cimgs[:-1]), "cliplabels_data": list(clabs[:-1])})))
+    calibrated_sd = {k: v.clone() for k, v in mod.state_dict().items()}
+    mod.eval()
+    store = {}
+    last = mod.ppm_conv.conv_last_ if method == "clip_psp" else mod.head
+    h = hook_output(last, store, "logits")
+    imgs = [torch.from_numpy(det_input("%s:eval:%d" % (tag, t), eval_shape)) for t in range(T)]
+    with torch.no_grad():
+        probs = mod({"img_data": imgs[-1], "clipimgs_data": imgs[:-1],
+                     "seg_label": torch.zeros(eval_shape[0], 1, *eval_shape[2:])}, segSize=eval_shape[2:])
+    h.remove()
+    for k, v in eval_pack(probs, store["logits"]).items():
+        res["eval_" + k] = v
+    mod.train()
+    imgs = [torch.from_numpy(det_input("%s:train:%d" % (tag, t), train_shape)) for t in range(T)]
+    labs = [torch.from_numpy(det_labels("%s:train:%d" % (tag, t), (train_shape[0], 1) + train_shape[2:], K))
+            for t in range(T)]
+    mod.zero_grad()
+    loss, acc = mod({"img_data": imgs[-1], "seg_label": labs[-1], "clipimgs_data": imgs[:-1],
+                     "cliplabels_data": labs[:-1]})
+    loss.backward()
+    res["train_loss"] = np.float64(loss.item())
+    res["train_acc"] = np.float64(acc.item())
+    full = ("encoder.conv1.weight", "encoder.layer1.0.conv2.weight", "encoder.layer4.2.bn3.weight")
+    res.update(grads_summary(mod, full=full))
+    eimgs = [torch.from_numpy(det_input("%s:eval:%d" % (tag, t), eval_shape)).double() for t in range(T)]
+    res.update(double_pass(
+        mod, calibrated_sd,
+        lambda: mod({"img_data": imgs[-1].double(), "seg_label": labs[-1].double(),
+                     "clipimgs_data": [i.double() for i in imgs[:-1]],
+                     "cliplabels_data": [l.double() for l in labs[:-1]]}),
+        last,
+        lambda: mod({"img_data": eimgs[-1], "clipimgs_data": list(eimgs[:-1]),
+                     "seg_label": torch.zeros(eval_shape[0], 1, *eval_shape[2:])}, segSize=eval_shape[2:])))
+    res["meta"] = np.array([arch, method, str(T), str(train_shape), str(eval_shape)])
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, "loss %.6f acc %.4f" % (loss.item(), acc.item()))
+
+
+def case_nonlocal3d(M, arch, tag, T=3, train_shape=(1, 3, 49, 49)):
+    torch.manual_seed(0)
+    enc = M.ModelBuilder.build_encoder(arch=arch, fc_dim=2048)
+    crit = torch.nn.NLLLoss(ignore_index=255)
+    mod = M.Non_local3d(args_ns(), enc, crit)
+    load_det(mod)
+    imgs = [torch.from_numpy(det_input("%s:train:%d" % (tag, t), train_shape)) for t in range(T)]
+    labs = [torch.from_numpy(det_labels("%s:train:%d" % (tag, t), (train_shape[0], 1) + train_shape[2:], K))
+            for t in range(T)]
+    res = calibrate_bn(mod, lambda: mod({"clipimgs_data": imgs, "cliplabels_data": labs}))
+    mod.train()
+    loss, acc = mod({"clipimgs_data": imgs, "cliplabels_data": labs})
+    loss.backward()
+    res.update({"train_loss": np.float64(loss.item()), "train_acc": np.float64(acc.item())})
+    res.update(grads_summary(mod, full=("nonlocalblock.theta.weight", "nonlocalblock.W_z.1.weight")))
+    mod.eval()
+    with torch.no_grad():
+        preds = mod({"clipimgs_data": imgs, "cliplabels_data": labs}, segSize=(49, 49))
+    res["eval_argmax"] = np.stack([p.numpy().argmax(1) for p in preds]).astype(np.uint8)
+    res["eval_margin"] = np.stack([top2_margin(p.numpy()) for p in preds])
+    res["eval_probs_sub"] = np.stack([p.numpy()[:, :, ::4, ::4] for p in preds])
+    res["meta"] = np.array([arch, "nonlocal3d", str(T), str(train_shape)])
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, "loss %.6f acc %.4f" % (loss.item(), acc.item()))
+
+
+def case_netwarp(M, arch, tag, shape=(2, 3, 65, 65)):
+    """NetWarp with the flow network replaced by a fixed synthetic field (the RAFT checkpoint is not in the tree):
+    pins FlowCNN, the nearest-resized un-rescaled flow, both flow-warps, the per-channel blends and the loss."""
+    import models.netwarp as ref_nw
+
+    class FakeRaft(torch.nn.Module):
+        def forward(self, a, b, iters=20, test_mode=True):
+            n, _, h, w = a.shape
+            f = torch.from_numpy(det_input(tag + ":flow", (n, 2, h, w), scale=1.9)) - 0.7
+            return None, f.clamp(-10, 10)
+
+    orig_raft, orig_load = ref_nw.RAFT, torch.load
+    ref_nw.RAFT = lambda: torch.nn.Identity()
+    torch.load = lambda *a, **k: {}
+    torch.manual_seed(0)
+    try:
+        enc = M.ModelBuilder.build_encoder(arch=arch, fc_dim=2048)
+        dec = M.ModelBuilder.build_decoder(arch="ppm_deepsup_clip", fc_dim=2048, num_class=K)
+        mod = M.NetWarp(enc, dec, torch.nn.NLLLoss(ignore_index=255), args_ns(clip_num=2), deep_sup_scale=0.4)
+    finally:
+        ref_nw.RAFT, torch.load = orig_raft, orig_load
+    mod.raft = FakeRaft()
+    sd = {k: v for k, v in mod.state_dict().items() if not k.startswith("raft.")}
+    mod.load_state_dict({k: torch.from_numpy(det_tensor(k, v.shape)).to(v.dtype) for k, v in sd.items()}, strict=False)
+    zero_dropout(mod)
+    mod.train()
+    cur = torch.from_numpy(det_input(tag + ":cur", shape))
+    prev = torch.from_numpy(det_input(tag + ":prev", shape))
+    lab = torch.from_numpy(det_labels(tag + ":lab", (shape[0], 1) + shape[2:], K))
+    loss, acc = mod({"img_data": cur, "seg_label": lab, "clipimgs_data": [prev], "cliplabels_data": []})
+    loss.backward()
+    res = {"train_loss": np.float64(loss.item()), "train_acc": np.float64(acc.item())}
+    res.update(grads_summary(mod, full=("w0_1", "w1_0", "flowcnn.conv4.0.weight")))
+    res["meta"] = np.array([arch, "netwarp", str(shape)])
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, "loss %.6f acc %.4f" % (loss.item(), acc.item()))
+
+
+def case_ops(M, tag="ops_reference"):
+    """Op-level vectors straight from the reference's own helper functions."""
+    import models.netwarp as ref_nw
+    from models.ocr_modules.spatial_ocr_block import SpatialGather_Module
+
+    res = {}
+    x = torch.from_numpy(det_input(tag + ":warp_x", (2, 6, 9, 11)))
+    flo = torch.from_numpy(det_input(tag + ":warp_f", (2, 2, 9, 11), scale=1.9)) - 0.7
+    flo[0, :, 0, 0] = torch.tensor([-30.0, 25.0])
+    res["flowwarp_flow"] = flo.numpy().copy()
+    res["flowwarp"] = ref_nw.flowwarp(x, flo).numpy()
+    feats = torch.from_numpy(det_input(tag + ":g_feats", (2, 32, 9, 13)))
+    probs = torch.from_numpy(det_input(tag + ":g_probs", (2, 7, 9, 13), scale=2.0))
+    res["ocr_gather"] = SpatialGather_Module(7)(feats, probs).numpy()
+    pa_pred = torch.from_numpy(det_input(tag + ":pa", (2, 5, 6, 7)))
+    pa_lab = torch.from_numpy(det_labels(tag + ":pa", (2, 1, 6, 7), 5)).squeeze(1).long()
+    res["pixel_acc"] = np.float64(M.models.SegmentationModuleBase().pixel_acc(pa_pred, pa_lab).item())
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, "done")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    M = import_reference()
+    only = set(sys.argv[1:])
+
+    def want(t):
+        return not only or t in only
+
+    if want("ops_reference"):
+        case_ops(M)
+    if want("r18_ppm_deepsup"):
+        case_segmodule(M, "resnet18dilated", "ppm_deepsup", "r18_ppm_deepsup", fc_dim=512)
+    if want("r50_clip_psp"):
+        case_clip(M, "clip_psp", "resnet50dilated", "r50_clip_psp")
+    if want("r50_clip_ocr"):
+        case_clip(M, "clip_ocr", "resnet50dilated", "r50_clip_ocr")
+    if want("r50_ocrnet_deepsup"):
+        case_segmodule(M, "resnet50dilated", "ocrnet_deepsup", "r50_ocrnet_deepsup", fc_dim=2048)
+    if want("r50_nonlocal2d"):
+        case_segmodule(M, "resnet50dilated", "nonlocal2d", "r50_nonlocal2d", fc_dim=2048)
+    if want("r50_nonlocal3d"):
+        case_nonlocal3d(M, "resnet50dilated", "r50_nonlocal3d")
+    if want("r50_netwarp"):
+        case_netwarp(M, "resnet50dilated", "r50_netwarp")
+
+
+if __name__ == "__main__":
+    main()

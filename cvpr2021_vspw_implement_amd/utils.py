@@ -1,0 +1,80 @@
+"""Evaluation helpers with the reference's definitions (utils.py:37-107): confusion-matrix Evaluator (pixel accuracy,
+class accuracy, mIoU over classes present in the ground truth, frequency-weighted IoU) and the video-consistency
+score `get_common`.  Host-side numpy, as in the reference."""
+import numpy as np
+
+
+class AverageMeter(object):
+    def __init__(self):
+        self.initialized = False
+        self.val = self.avg = self.sum = self.count = None
+
+    def update(self, val, weight=1):
+        if not self.initialized:
+            self.val, self.avg, self.sum, self.count, self.initialized = val, val, val * weight, weight, True
+        else:
+            self.val = val
+            self.sum += val * weight
+            self.count += weight
+            self.avg = self.sum / self.count
+
+    def value(self):
+        return self.val
+
+    def average(self):
+        return self.avg
+
+
+class Evaluator(object):
+    def __init__(self, num_class):
+        self.num_class = num_class
+        self.confusion_matrix = np.zeros((num_class, num_class))
+
+    def reset(self):
+        self.confusion_matrix = np.zeros((self.num_class, self.num_class))
+
+    def add_batch(self, gt_image, pre_image):
+        assert gt_image.shape == pre_image.shape
+        keep = (gt_image >= 0) & (gt_image < self.num_class)
+        idx = self.num_class * gt_image[keep].astype("int") + pre_image[keep]
+        self.confusion_matrix += np.bincount(idx, minlength=self.num_class ** 2).reshape(self.num_class,
+                                                                                         self.num_class)
+
+    def beforeval(self):
+        present = self.confusion_matrix.sum(axis=1) > 0
+        self.confusion_matrix = self.confusion_matrix * present
+
+    def Pixel_Accuracy(self):
+        return np.diag(self.confusion_matrix).sum() / self.confusion_matrix.sum()
+
+    def Pixel_Accuracy_Class(self):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.nanmean(np.diag(self.confusion_matrix) / self.confusion_matrix.sum(axis=1))
+
+    def _iou(self):
+        cm = self.confusion_matrix
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.diag(cm) / (cm.sum(axis=1) + cm.sum(axis=0) - np.diag(cm))
+
+    def Mean_Intersection_over_Union(self):
+        present = self.confusion_matrix.sum(axis=1) > 0
+        return np.nansum(self._iou() * present) / present.sum()
+
+    def Frequency_Weighted_Intersection_over_Union(self):
+        freq = self.confusion_matrix.sum(axis=1) / self.confusion_matrix.sum()
+        iu = self._iou()
+        return (freq[freq > 0] * iu[freq > 0]).sum()
+
+
+def get_common(gt_list, pred_list, clip_num, h, w):
+    """Video consistency VC_n (reference utils.py:37-53): over every window of clip_num frames, the fraction of
+    pixels whose ground truth is constant across the window that are also predicted constantly AND..."""
+    accs = []
+    for i in range(len(gt_list) - clip_num):
+        gt_same = np.ones((h, w), dtype=bool)
+        pr_same = np.ones((h, w), dtype=bool)
+        for j in range(1, clip_num):
+            gt_same &= gt_list[i] == gt_list[i + j]
+            pr_same &= pred_list[i] == pred_list[i + j]
+        accs.append((pr_same & gt_same).sum() / gt_same.sum())
+    return accs

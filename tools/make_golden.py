@@ -321,6 +321,69 @@ def case_ops(M, tag="ops_reference"):
     print(tag, "done")
 
 
+def case_keys(M, tag="state_keys"):
+    """state_dict key names / shapes and the 4 SGD parameter-group listings of the reference's modules
+    (the drop-in contract of SURVEY.md 8b), for the CPU host-logic tests."""
+    import models.netwarp as ref_nw
+
+    res = {}
+    crit = torch.nn.NLLLoss(ignore_index=255)
+
+    def record(name, mod, groups=True):
+        sd = mod.state_dict()
+        res[name + ":keys"] = np.array(list(sd.keys()))
+        res[name + ":shapes"] = np.array([str(tuple(v.shape)) for v in sd.values()])
+        if groups:
+            ids = {id(p): k for k, p in mod.named_parameters()}
+            for g in ("get_1x_lr_params", "get_10x_lr_params", "get_1x_lr_params_bias", "get_10x_lr_params_bias"):
+                res["%s:%s" % (name, g)] = np.array([ids[id(p)] for p in getattr(mod, g)()])
+
+    for arch in ("resnet50dilated", "resnet101dilated"):
+        enc = M.ModelBuilder.build_encoder(arch=arch, fc_dim=2048)
+        record("clip_psp:" + arch, M.Clip_PSP(enc, crit, args_ns(), deep_sup_scale=0.4))
+        enc = M.ModelBuilder.build_encoder(arch=arch, fc_dim=2048)
+        record("clip_ocr:" + arch, M.ClipOCRNet(enc, crit, args_ns(), deep_sup_scale=0.4))
+    enc = M.ModelBuilder.build_encoder(arch="resnet50dilated", fc_dim=2048)
+    record("clip_psp_pspw:resnet50dilated", M.Clip_PSP(enc, crit, args_ns(psp_weight=True), deep_sup_scale=0.4))
+    enc = M.ModelBuilder.build_encoder(arch="resnet50dilated", fc_dim=2048)
+    record("nonlocal3d:resnet50dilated", M.Non_local3d(args_ns(), enc, crit))
+    for arch, dec, fc in (("resnet18dilated", "ppm_deepsup", 512), ("resnet101dilated", "ppm_deepsup", 2048),
+                          ("resnet50dilated", "ocrnet_deepsup", 2048), ("resnet50dilated", "nonlocal2d", 2048),
+                          ("resnet50dilated", "ppm_deepsup_clip", 2048), ("resnet50dilated", "ppm", 2048),
+                          ("resnet50", "ppm_clip", 2048)):
+        enc = M.ModelBuilder.build_encoder(arch=arch, fc_dim=fc)
+        d = M.ModelBuilder.build_decoder(arch=dec, fc_dim=fc, num_class=K)
+        record("seg:%s:%s" % (arch, dec), M.SegmentationModule(enc, d, crit, 0.4), groups=False)
+    orig_raft, orig_load = ref_nw.RAFT, torch.load
+    ref_nw.RAFT = lambda: torch.nn.Identity()
+    torch.load = lambda *a, **k: {}
+    try:
+        enc = M.ModelBuilder.build_encoder(arch="resnet50dilated", fc_dim=2048)
+        d = M.ModelBuilder.build_decoder(arch="ppm_deepsup_clip", fc_dim=2048, num_class=K)
+        nw = M.NetWarp(enc, d, crit, args_ns(clip_num=2), deep_sup_scale=0.4)
+    finally:
+        ref_nw.RAFT, torch.load = orig_raft, orig_load
+    sd = nw.state_dict()
+    res["netwarp:resnet50dilated:keys"] = np.array([k for k in sd if not k.startswith("raft.")])
+    res["netwarp:resnet50dilated:shapes"] = np.array([str(tuple(v.shape)) for k, v in sd.items()
+                                                      if not k.startswith("raft.")])
+    # BN init of build_decoder(weights_init) and default conv geometry after _nostride_dilate
+    enc = M.ModelBuilder.build_encoder(arch="resnet101dilated", fc_dim=2048)
+    geo = []
+    for k, m in enc.named_modules():
+        if isinstance(m, torch.nn.Conv2d):
+            geo.append("%s %s %s %s %s" % (k, m.kernel_size, m.stride, m.padding, m.dilation))
+    res["geometry:resnet101dilated"] = np.array(geo)
+    enc = M.ModelBuilder.build_encoder(arch="resnet18dilated", fc_dim=512)
+    geo = []
+    for k, m in enc.named_modules():
+        if isinstance(m, torch.nn.Conv2d):
+            geo.append("%s %s %s %s %s" % (k, m.kernel_size, m.stride, m.padding, m.dilation))
+    res["geometry:resnet18dilated"] = np.array(geo)
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, "done")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -330,6 +393,8 @@ def main():
     def want(t):
         return not only or t in only
 
+    if want("state_keys"):
+        case_keys(M)
     if want("ops_reference"):
         case_ops(M)
     if want("r18_ppm_deepsup"):

@@ -276,3 +276,37 @@ extern "C" int vspw_flowwarp_bwd(const float* dy, const float* x, const float* f
                        vspw_stream(stream), dy, x, flow, dx, dflow, n, h, w, c);
     return vspw_launch_status();
 }
+
+// ---- SGD with momentum / weight decay, `mult` sequential applications -----------------------------------------
+// torch.optim.SGD semantics (train_clip2.py:215-236: momentum 0.9, weight_decay per group, dampening 0, no nesterov)
+// applied `mult` times in a row with the same gradient: the reference's get_*_lr_params generators yield a parameter
+// once per enclosing module, and torch.optim.SGD (1.3.1, a plain Python loop) then updates it once per occurrence.
+//   d = g + wd*p ; buf = first ? d : momentum*buf + d ; p -= lr*buf
+__global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ buf, long long n, float lr, float wd,
+                                                       float momentum, int mult, int first) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float pv = p[i];
+        const float gv = g[i];
+        float bv = first ? 0.f : buf[i];
+        bool have = !first;
+        for (int r = 0; r < mult; ++r) {
+            const float d = gv + wd * pv;
+            bv = have ? momentum * bv + d : d;
+            have = true;
+            pv -= lr * bv;
+        }
+        p[i] = pv;
+        buf[i] = bv;
+    }
+}
+
+extern "C" int vspw_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float wd, float momentum,
+                             int mult, int first, void* stream) {
+    if (!p || !g || !buf || n <= 0 || mult <= 0) return VSPW_EINVAL;
+    hipLaunchKernelGGL(sgd_step_kernel, dim3(vspw_stream_grid(n, 256)), dim3(256), 0, vspw_stream(stream), p, g, buf,
+                       n, lr, wd, momentum, mult, first);
+    return vspw_launch_status();
+}

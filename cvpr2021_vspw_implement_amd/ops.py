@@ -66,6 +66,45 @@ def _conv_desc(x, k, kh, kw, stride, pad, dil):
     return ConvDesc(n, h, w, c, oh, ow, k, kh, kw, stride, pad, dil)
 
 
+# Optional per-launch timing of the MFMA GEMM kernels (bench.py's roofline leg): HIP events are recorded on the
+# stream the kernels are launched on (torch's current stream) around every igemm launch.
+_ktimer = {"on": False, "records": []}
+
+
+def kernel_timer(enable):
+    _ktimer["on"] = bool(enable)
+    if enable:
+        _ktimer["records"] = []
+
+
+def kernel_timer_records():
+    """[(kernel name, algorithmic flops, ms)] for every timed launch (synchronises)."""
+    torch.cuda.synchronize()
+    return [(n, f, e0.elapsed_time(e1)) for n, f, e0, e1 in _ktimer["records"]]
+
+
+class _Timed:
+    def __init__(self, name, flops):
+        self.name, self.flops = name, flops
+
+    def __enter__(self):
+        if _ktimer["on"]:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if _ktimer["on"]:
+            self.e1.record()
+            _ktimer["records"].append((self.name, self.flops, self.e0, self.e1))
+        return False
+
+
+def _conv_flops(d):
+    return 2.0 * d.n * d.oh * d.ow * d.k * d.kh * d.kw * d.c
+
+
 def _ws(nbytes, device):
     return torch.empty((max(int(nbytes), 8) + 7) // 8, device=device, dtype=torch.float64)
 
@@ -86,7 +125,8 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False):
     if want_stats:
         tiles = _C.query("vspw_conv2d_stats_partials", ctypes.byref(d))
         part = torch.empty((tiles, 2, k), device=x.device, dtype=torch.float32)
-    _C.call("vspw_conv2d_fwd", ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y), _p(part), _stream())
+    with _Timed("igemm_nt_kernel", _conv_flops(d)):
+        _C.call("vspw_conv2d_fwd", ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y), _p(part), _stream())
     return y, part, d
 
 
@@ -95,7 +135,8 @@ def conv2d_backward_data(dy, w, d):
     wT = torch.empty((c, kh, kw, k), device=w.device, dtype=torch.float32)
     _C.call("vspw_weight_transpose", _p(w), _p(wT), k, kh * kw, c, _stream())
     dx = empty_nhwc(d.n, d.c, d.h, d.w, dy.device)
-    _C.call("vspw_conv2d_bwd_data", ctypes.byref(d), _p(dy), _p(wT), _p(dx), _stream())
+    with _Timed("igemm_nt_kernel", _conv_flops(d)):
+        _C.call("vspw_conv2d_bwd_data", ctypes.byref(d), _p(dy), _p(wT), _p(dx), _stream())
     return dx
 
 
@@ -103,7 +144,8 @@ def conv2d_backward_weight(dy, x, d):
     dw = torch.empty((d.k, d.kh, d.kw, d.c), device=dy.device, dtype=torch.float32).permute(0, 3, 1, 2)
     nbytes = _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d))
     ws = _ws(nbytes, dy.device) if nbytes else None
-    _C.call("vspw_conv2d_bwd_weight", ctypes.byref(d), _p(dy), _p(x), _p(dw), _p(ws), nbytes, _stream())
+    with _Timed("igemm_tn_kernel", _conv_flops(d)):
+        _C.call("vspw_conv2d_bwd_weight", ctypes.byref(d), _p(dy), _p(x), _p(dw), _p(ws), nbytes, _stream())
     return dw
 
 

@@ -176,6 +176,12 @@ int vspw_flowwarp_fwd(const float* x, const float* flow, float* y, int n, int h,
 int vspw_flowwarp_bwd(const float* dy, const float* x, const float* flow, float* dx, float* dflow, int n, int h,
                       int w, int c, void* stream);
 
+/* torch.optim.SGD(momentum, weight_decay) update applied `mult` times with the same gradient (the reference's
+ * parameter-group generators yield a parameter once per enclosing module, train_clip2.py:215-236 +
+ * models/clip_psp.py:99-135).  p, g, buf are dense tensors with identical strides; first != 0 initialises buf. */
+int vspw_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float wd, float momentum, int mult,
+                  int first, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,7 +50,7 @@ class NLBlockND(nn.Module):
         n_pos = 1
         for s in shape[2:]:
             n_pos *= s
-        xr = ops.to_nhwc(x.reshape(b, c, n_pos, 1))  # [B,C,N,1]: rows = positions
+        xr = ops.as_nhwc(x.reshape(b, c, n_pos, 1))  # [B,C,N,1]: rows = positions
         g = ops.pixels_view(ops.conv2d(xr, self._w2d(self.g), self.g.bias))  # [B,N,Ci]
         th = ops.pixels_view(ops.conv2d(xr, self._w2d(self.theta), self.theta.bias))
         ph = ops.pixels_view(ops.conv2d(xr, self._w2d(self.phi), self.phi.bias))

@@ -968,9 +968,26 @@ def channel_cat(xs):
     return ChannelCatFn.apply(*xs)
 
 
+class _AsNHWCFn(torch.autograd.Function):
+    """Layout change NCHW-memory -> NHWC-memory that stays on the autograd graph (identity for gradients)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return to_nhwc(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def as_nhwc(x):
+    """Differentiable to_nhwc: use this (not to_nhwc) on tensors that may require grad outside a Function."""
+    return x if is_nhwc(x) else _AsNHWCFn.apply(x)
+
+
 def pixels_view(x):
     """NHWC-memory [N,C,H,W] -> zero-copy [N, H*W, C] view (rows = pixels)."""
-    x = to_nhwc(x)
+    x = as_nhwc(x)
     n, c, h, w = x.shape
     return x.permute(0, 2, 3, 1).reshape(n, h * w, c)
 

@@ -83,19 +83,26 @@ def clip_inputs(tag, T=3, train_shape=(2, 3, 65, 65), eval_shape=(1, 3, 64, 96))
     )
 
 
-def check_grad_norms(named_grads, fx, rtol, what):
-    """named_grads: {name: ndarray}; fixture holds grad_names / grad_norms from the reference."""
+def check_grad_norms(named_grads, fx, rtol, what, agg_rtol=None):
+    """named_grads: {name: ndarray}; fixture holds grad_names / grad_norms from the reference.
+    Per-parameter relative error <= rtol and (optionally) the error of the whole vector of norms <= agg_rtol."""
     names = [str(n) for n in fx["grad_names"]]
     ref = dict(zip(names, fx["grad_norms"]))
     scale = max(ref.values())
     worst = (0.0, None)
+    num = den = 0.0
     for n, r in ref.items():
         assert n in named_grads, "%s: no gradient for %s" % (what, n)
         g = float(np.linalg.norm(named_grads[n].astype(np.float64)))
         err = abs(g - r) / max(r, 1e-3 * scale)
+        num += (g - r) ** 2
+        den += r ** 2
         if err > worst[0]:
             worst = (err, n)
     assert worst[0] <= rtol, "%s: grad-norm mismatch %.3e at %s" % (what, worst[0], worst[1])
+    if agg_rtol is not None:
+        agg = (num / den) ** 0.5
+        assert agg <= agg_rtol, "%s: aggregate grad-norm error %.3e" % (what, agg)
     return worst
 
 

@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--kernel-report", default="", help="write a per-shape GEMM efficiency table to this file")
     ap.add_argument("--method", default="clip_psp", choices=["clip_psp", "clip_ocr"])
     args = ap.parse_args()
 
@@ -143,7 +144,20 @@ def main():
 
     roofline = None
     if not args.no_kernel_timing:
-        recs = [r for r in ops.kernel_timer_records() if r[0] == "igemm_nt_kernel"]
+        allrecs = ops.kernel_timer_records()
+        if args.kernel_report and rank == 0:
+            agg = {}
+            for name, fl, ms, tag in allrecs:
+                a = agg.setdefault(tag, [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += fl
+                a[2] += ms
+            with open(args.kernel_report, "w") as f:
+                f.write("shape,launches_per_step,gflop_per_launch,avg_ms,tflops,ms_per_step\n")
+                for tag, (cnt, fl, ms) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+                    f.write("%s,%.1f,%.2f,%.4f,%.1f,%.3f\n" % (tag, cnt / args.steps, fl / cnt / 1e9, ms / cnt,
+                                                             fl / ms / 1e9, ms / args.steps))
+        recs = [r for r in allrecs if r[0] == "igemm_nt_kernel"]
         if recs:
             flops = sum(r[1] for r in recs)
             ms = sum(r[2] for r in recs)

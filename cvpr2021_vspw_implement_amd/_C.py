@@ -33,6 +33,10 @@ def _arg_ctype(decl: str):
     if "*" in decl:
         if "vspw_conv_desc" in decl:
             return ctypes.POINTER(ConvDesc)
+        if "float* const*" in decl:
+            return ctypes.POINTER(ctypes.c_void_p)
+        if decl.startswith("const int*"):
+            return ctypes.POINTER(ctypes.c_int)
         return ctypes.c_void_p
     # strip the parameter name
     toks = decl.replace("const ", "").split()

@@ -69,22 +69,30 @@ __global__ __launch_bounds__(RED_TX * RED_TY) void bn_stats_kernel(const float* 
     }
 }
 
-__global__ void reduce_partials_f64_kernel(const double* __restrict__ part, double* __restrict__ sums, int splits,
-                                           int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double a = 0;
-    for (int z = 0; z < splits; ++z) a += part[(size_t)z * n + i];
-    sums[i] = a;
-}
-
-__global__ void reduce_partials_f32_kernel(const float* __restrict__ part, double* __restrict__ sums, int tiles,
-                                           int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double a = 0;
-    for (int z = 0; z < tiles; ++z) a += (double)part[(size_t)z * n + i];
-    sums[i] = a;
+// sums[i] = sum_z part[z][i]: 64 columns x 16 row-lanes per workgroup, coalesced rows, LDS tree at the end.
+template <typename T>
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const T* __restrict__ part, double* __restrict__ sums,
+                                                               int splits, int n) {
+    __shared__ double red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + tx;
+    double a0 = 0, a1 = 0;
+    if (col < n) {
+        int z = ty;
+        for (; z + 16 < splits; z += 32) {
+            a0 += (double)part[(size_t)z * n + col];
+            a1 += (double)part[(size_t)(z + 16) * n + col];
+        }
+        if (z < splits) a0 += (double)part[(size_t)z * n + col];
+    }
+    red[ty][tx] = a0 + a1;
+    __syncthreads();
+    if (ty == 0 && col < n) {
+        double a = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a += red[j][tx];
+        sums[col] = a;
+    }
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
@@ -174,6 +182,7 @@ __global__ __launch_bounds__(RED_TX * RED_TY) void bn_bwd_reduce_kernel(
     const int tx = threadIdx.x, ty = threadIdx.y;
     const int c0 = (blockIdx.x * RED_TX + tx) * 4;
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const bool vec = (c % 4 == 0);
     if (c0 < c) {
         float mu[4], is[4];
 #pragma unroll
@@ -183,16 +192,28 @@ __global__ __launch_bounds__(RED_TX * RED_TY) void bn_bwd_reduce_kernel(
         }
         for (long long r = (long long)blockIdx.y * RED_TY + ty; r < rows; r += (long long)gridDim.y * RED_TY) {
             const size_t off = (size_t)r * c + c0;
+            f32x4 g = {0.f, 0.f, 0.f, 0.f}, zv = {1.f, 1.f, 1.f, 1.f}, xv = {0.f, 0.f, 0.f, 0.f};
+            if (vec) {
+                g = *reinterpret_cast<const f32x4*>(dz + off);
+                xv = *reinterpret_cast<const f32x4*>(x + off);
+                if (relu) zv = *reinterpret_cast<const f32x4*>(z + off);
+                if (mask) g *= *reinterpret_cast<const f32x4*>(mask + (size_t)(r / rpi) * c + c0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + e < c) {
+                        g[e] = dz[off + e];
+                        xv[e] = x[off + e];
+                        if (relu) zv[e] = z[off + e];
+                        if (mask) g[e] *= mask[(size_t)(r / rpi) * c + c0 + e];
+                    }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (c0 + e < c) {
-                    float g = dz[off + e];
-                    if (mask) g *= mask[(size_t)(r / rpi) * c + c0 + e];
-                    if (relu && !(z[off + e] > 0.f)) g = 0.f;
-                    float xh = (x[off + e] - mu[e]) * is[e];
-                    s[e] += (double)g;
-                    q[e] += (double)g * (double)xh;
-                }
+                const float ge = (relu && !(zv[e] > 0.f)) ? 0.f : g[e];
+                const float xh = (xv[e] - mu[e]) * is[e];
+                s[e] += (double)ge;
+                q[e] += (double)ge * (double)xh;
             }
         }
     }
@@ -234,25 +255,54 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         const long long r = i / cw;
         const int ch = (int)(i - r * cw) * W;
         const size_t off = (size_t)r * c + ch;
+        if (VEC) {
+            f32x4 g = *reinterpret_cast<const f32x4*>(dz + off);
+            if (mask) g *= *reinterpret_cast<const f32x4*>(mask + (size_t)(r / rpi) * c + ch);
+            if (relu) {
+                const f32x4 zv = *reinterpret_cast<const f32x4*>(z + off);
 #pragma unroll
-        for (int e = 0; e < W; ++e) {
-            float g = dz[off + e];
-            if (mask) g *= mask[(size_t)(r / rpi) * c + ch + e];
-            if (relu && !(z[off + e] > 0.f)) g = 0.f;
-            if (dres) dres[off + e] = g;
+                for (int e = 0; e < 4; ++e)
+                    if (!(zv[e] > 0.f)) g[e] = 0.f;
+            }
+            if (dres) *reinterpret_cast<f32x4*>(dres + off) = g;
             if (dx) {
-                float is = invstd[ch + e];
-                float gm = gamma ? gamma[ch + e] : 1.f;
+                const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + ch);
+                f32x4 gm = {1.f, 1.f, 1.f, 1.f};
+                if (gamma) gm = *reinterpret_cast<const f32x4*>(gamma + ch);
+                f32x4 o;
+                if (training) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4*>(x + off);
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + ch);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (xv[e] - mu[e]) * is[e];
+                        const float mg = (float)(sums[ch + e] * inv_count);
+                        const float mgx = (float)(sums[c + ch + e] * inv_count);
+                        o[e] = gm[e] * is[e] * (g[e] - mg - xh * mgx);
+                    }
+                } else {
+                    o = gm * is * g;
+                }
+                *reinterpret_cast<f32x4*>(dx + off) = o;
+            }
+        } else {
+            float g = dz[off];
+            if (mask) g *= mask[(size_t)(r / rpi) * c + ch];
+            if (relu && !(z[off] > 0.f)) g = 0.f;
+            if (dres) dres[off] = g;
+            if (dx) {
+                const float is = invstd[ch];
+                const float gm = gamma ? gamma[ch] : 1.f;
                 float o;
                 if (training) {
-                    float xh = (x[off + e] - mean[ch + e]) * is;
-                    float mg = (float)(sums[ch + e] * inv_count);
-                    float mgx = (float)(sums[c + ch + e] * inv_count);
+                    const float xh = (x[off] - mean[ch]) * is;
+                    const float mg = (float)(sums[ch] * inv_count);
+                    const float mgx = (float)(sums[c + ch] * inv_count);
                     o = gm * is * (g - mg - xh * mgx);
                 } else {
                     o = gm * is * g;
                 }
-                dx[off + e] = o;
+                dx[off] = o;
             }
         }
     }
@@ -268,8 +318,8 @@ __global__ void bn_param_grads_kernel(const double* __restrict__ sums, float* __
 
 static void reduce_plan(long long rows, int c, int& gx, int& gy) {
     gx = vspw_cdiv(c, RED_TX * 4);
-    long long want = (2048 + gx - 1) / gx;
-    long long maxy = (rows + RED_TY - 1) / RED_TY;
+    long long want = (1024 + gx - 1) / gx;
+    long long maxy = (rows + RED_TY * 4 - 1) / (RED_TY * 4);
     if (want > maxy) want = maxy;
     if (want < 1) want = 1;
     gy = (int)want;
@@ -291,14 +341,14 @@ extern "C" int vspw_bn_stats(const float* x, long long rows, int c, double* sums
     if (!ws || ws_bytes < (size_t)gy * 2 * c * sizeof(double)) return VSPW_EINVAL;
     double* part = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL(bn_stats_kernel, dim3(gx, gy), dim3(RED_TX, RED_TY), 0, vspw_stream(stream), x, rows, c, part);
-    hipLaunchKernelGGL(reduce_partials_f64_kernel, dim3(vspw_cdiv(2 * c, 256)), dim3(256), 0, vspw_stream(stream),
-                       part, sums, gy, 2 * c);
+    hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3(vspw_cdiv(2 * c, 64)), dim3(1024), 0, vspw_stream(stream),
+                       (const double*)part, sums, gy, 2 * c);
     return vspw_launch_status();
 }
 
 extern "C" int vspw_bn_reduce_partials_f32(const float* part, int tiles, int c, double* sums, void* stream) {
     if (!part || !sums || tiles <= 0 || c <= 0) return VSPW_EINVAL;
-    hipLaunchKernelGGL(reduce_partials_f32_kernel, dim3(vspw_cdiv(2 * c, 256)), dim3(256), 0, vspw_stream(stream),
+    hipLaunchKernelGGL(reduce_partials_kernel<float>, dim3(vspw_cdiv(2 * c, 64)), dim3(1024), 0, vspw_stream(stream),
                        part, sums, tiles, 2 * c);
     return vspw_launch_status();
 }
@@ -353,8 +403,8 @@ extern "C" int vspw_bn_bwd_reduce(const float* dz, const float* z, const float* 
     double* part = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(gx, gy), dim3(RED_TX, RED_TY), 0, vspw_stream(stream), dz, z, x, mean,
                        invstd, chan_mask, rows, c, rows_per_image, relu, part);
-    hipLaunchKernelGGL(reduce_partials_f64_kernel, dim3(vspw_cdiv(2 * c, 256)), dim3(256), 0, vspw_stream(stream),
-                       part, sums, gy, 2 * c);
+    hipLaunchKernelGGL(reduce_partials_kernel<double>, dim3(vspw_cdiv(2 * c, 64)), dim3(1024), 0, vspw_stream(stream),
+                       (const double*)part, sums, gy, 2 * c);
     return vspw_launch_status();
 }
 

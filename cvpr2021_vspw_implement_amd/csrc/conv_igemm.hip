@@ -60,9 +60,23 @@ __device__ __forceinline__ bool nt_src_coord(const IgemmNT& p, int by, int bx, i
     }
 }
 
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch, used for speed only); give every XCD a
+// contiguous range of tiles so that the N-tiles of one M-tile (same gathered pixels) and neighbouring M-tiles (shared
+// 3x3 halo rows) hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+// WM x WN = MFMA 32x32 tiles per wave; 2x2 waves -> workgroup tile (64*WM) x (64*WN).
+template <int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
-    __shared__ __attribute__((aligned(16))) float As[BM * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDA];
+    constexpr int TM = 64 * WM, TN = 64 * WN;
+    constexpr int RA = TM / 32, RB = TN / 32;  // rows staged per thread
+    __shared__ __attribute__((aligned(16))) float As[TM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[TN * LDA];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -70,20 +84,21 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    const int tiles_n = (p.nout + BN - 1) / BN;
-    const int tile_n = blockIdx.x % tiles_n;
-    const int tile_m = blockIdx.x / tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int tiles_n = (p.nout + TN - 1) / TN;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = vb % tiles_n;
+    const int tile_m = vb / tiles_n;
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
 
     const int lrow = tid >> 3;       // 0..31
     const int lcol = (tid & 7) * 4;  // 0,4,..,28
 
-    // Row (pixel) decode for the 4 A rows this thread stages; independent of k.
-    int a_img[4], a_by[4], a_bx[4];
-    bool a_ok[4];
+    // Row (pixel) decode for the A rows this thread stages; independent of k.
+    int a_img[RA], a_by[RA], a_bx[RA];
+    bool a_ok[RA];
     const int ohw = p.oh * p.ow;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RA; ++i) {
         int m = m0 + lrow + 32 * i;
         a_ok[i] = m < p.m;
         int mm = a_ok[i] ? m : 0;
@@ -100,16 +115,16 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
             a_bx[i] = ox + p.pad;
         }
     }
-    bool b_ok[4];
-    size_t b_off[4];
+    bool b_ok[RB];
+    size_t b_off[RB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RB; ++i) {
         int n = n0 + lrow + 32 * i;
         b_ok[i] = n < p.nout;
         b_off[i] = (size_t)(b_ok[i] ? n : 0) * (size_t)p.kdim;
     }
 
-    f32x4 ra[4], rb[4];
+    f32x4 ra[RA], rb[RB];
 
     auto load_tile = [&](int k0) {
         const int k4 = k0 + lcol;
@@ -123,7 +138,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
                 kx = tap - ky * p.kw;
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RA; ++i) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 int sy, sx;
                 if (kin && a_ok[i] && nt_src_coord(p, a_by[i], a_bx[i], ky, kx, sy, sx)) {
@@ -131,15 +146,17 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
                     v = *reinterpret_cast<const f32x4*>(p.src + off);
                 }
                 ra[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
                 f32x4 wv = {0.f, 0.f, 0.f, 0.f};
                 if (kin && b_ok[i]) wv = *reinterpret_cast<const f32x4*>(p.wt + b_off[i] + k4);
                 rb[i] = wv;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RA; ++i) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                f32x4 wv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     int k = k4 + e;
@@ -153,20 +170,26 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
                             size_t off = (((size_t)a_img[i] * p.h + sy) * p.w + sx) * (size_t)p.c + ci;
                             v[e] = p.src[off];
                         }
-                        if (b_ok[i]) wv[e] = p.wt[b_off[i] + k];
                     }
                 }
                 ra[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                f32x4 wv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k4 + e < p.kdim && b_ok[i]) wv[e] = p.wt[b_off[i] + k4 + e];
                 rb[i] = wv;
             }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[WM][WN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -174,45 +197,47 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
     load_tile(0);
     for (int kt = 0; kt < nk; ++kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * LDA + lcol]) = ra[i];
-            *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * LDA + lcol]) = rb[i];
-        }
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&As[(lrow + 32 * i) * LDA + lcol]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bs[(lrow + 32 * i) * LDA + lcol]) = rb[i];
         __syncthreads();
         if (kt + 1 < nk) load_tile((kt + 1) * BK);
         // Each lane half (lh) owns 4 consecutive k of every 8-k chunk; MFMA step s pairs
         // k = 8*kc + s (lanes 0-31) with k = 8*kc + 4 + s (lanes 32-63) for both operands.
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
-            f32x4 a[2], b[2];
+            f32x4 a[WM], b[WN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *reinterpret_cast<const f32x4*>(&As[(wm * 64 + i * 32 + l31) * LDA + kc * 8 + 4 * lh]);
-                b[i] = *reinterpret_cast<const f32x4*>(&Bs[(wn * 64 + i * 32 + l31) * LDA + kc * 8 + 4 * lh]);
-            }
+            for (int i = 0; i < WM; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(&As[(wm * 32 * WM + i * 32 + l31) * LDA + kc * 8 + 4 * lh]);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                b[j] = *reinterpret_cast<const f32x4*>(&Bs[(wn * 32 * WN + j * 32 + l31) * LDA + kc * 8 + 4 * lh]);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
 
     // Epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+    float csum[WN], csq[WN];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < WN; ++j) {
+        csum[j] = 0.f;
+        csq[j] = 0.f;
+        const int col = n0 + wn * 32 * WN + j * 32 + l31;
         const bool cok = col < p.nout;
         const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < WM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (cok && row < p.m) {
                     float v = acc[i][j][r] + bv;
                     p.dst[(size_t)row * p.ldd + col] = v;
@@ -224,28 +249,54 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
     }
     if (p.stat_part != nullptr) {
         // Per-tile column partial sums: lanes l and l^32 share a column; so do waves wm=0/1.
-        float* red = As;  // reuse LDS: [2 stats][2 wm][128 cols]
+        float* red = As;  // reuse LDS: [2 stats][2 wm][TN cols]  (TM*LDA >= 4*TN always)
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < WN; ++j) {
             float s = csum[j] + __shfl_xor(csum[j], 32, 64);
             float q = csq[j] + __shfl_xor(csq[j], 32, 64);
             if (lh == 0) {
-                int c = wn * 64 + j * 32 + l31;
-                red[(0 * 2 + wm) * 128 + c] = s;
-                red[(1 * 2 + wm) * 128 + c] = q;
+                int c = wn * 32 * WN + j * 32 + l31;
+                red[(0 * 2 + wm) * TN + c] = s;
+                red[(1 * 2 + wm) * TN + c] = q;
             }
         }
         __syncthreads();
-        if (tid < 128) {
+        if (tid < TN) {
             int col = n0 + tid;
             if (col < p.nout) {
                 float* out = p.stat_part + (size_t)tile_m * 2 * p.nout;
-                out[col] = red[0 * 128 + tid] + red[1 * 128 + tid];
-                out[p.nout + col] = red[2 * 128 + tid] + red[3 * 128 + tid];
+                out[col] = red[0 * TN + tid] + red[1 * TN + tid];
+                out[p.nout + col] = red[2 * TN + tid] + red[3 * TN + tid];
             }
         }
     }
+}
+
+// Tile choice: fp32 MFMA work is uniform per tile, so the only scheduling loss is the tail; prefer the big tile
+// (fewest LDS/global bytes per FLOP) when it still yields >= 4 workgroups per CU, otherwise halve the tile.
+static int nt_pick_tile(long long m, int nout) {
+    const long long b22 = ((m + 127) / 128) * ((nout + 127) / 128);
+    if (b22 >= 1024) return 22;
+    const long long b12 = ((m + 63) / 64) * ((nout + 127) / 128);
+    if (b12 >= 1024 || nout > 64) return 12;
+    return 11;
+}
+
+static int nt_tile_rows(int cfg) { return cfg == 22 ? 128 : 64; }
+
+static int launch_igemm_nt(const IgemmNT& p, int cfg, hipStream_t st) {
+    if (cfg == 22) {
+        int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
+        hipLaunchKernelGGL((igemm_nt_kernel<2, 2>), dim3(tiles), dim3(256), 0, st, p);
+    } else if (cfg == 12) {
+        int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
+        hipLaunchKernelGGL((igemm_nt_kernel<1, 2>), dim3(tiles), dim3(256), 0, st, p);
+    } else {
+        int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
+        hipLaunchKernelGGL((igemm_nt_kernel<1, 1>), dim3(tiles), dim3(256), 0, st, p);
+    }
+    return vspw_launch_status();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -449,7 +500,8 @@ static int conv_geometry_ok(const vspw_conv_desc* d) {
 extern "C" size_t vspw_conv2d_stats_partials(const vspw_conv_desc* d) {
     if (!d) return 0;
     long long m = (long long)d->n * d->oh * d->ow;
-    return (size_t)((m + BM - 1) / BM);
+    const int rows = nt_tile_rows(nt_pick_tile(m, d->k));
+    return (size_t)((m + rows - 1) / rows);
 }
 
 extern "C" int vspw_conv2d_fwd(const vspw_conv_desc* d, const float* x, const float* w, const float* bias,
@@ -467,9 +519,7 @@ extern "C" int vspw_conv2d_fwd(const vspw_conv_desc* d, const float* x, const fl
     p.m = (int)m;
     p.kdim = d->kh * d->kw * d->c;
     p.vec = (d->c % 4 == 0) ? 1 : 0;
-    int tiles = vspw_cdiv(p.m, BM) * vspw_cdiv(p.nout, BN);
-    hipLaunchKernelGGL(igemm_nt_kernel, dim3(tiles), dim3(256), 0, vspw_stream(stream), p);
-    return vspw_launch_status();
+    return launch_igemm_nt(p, nt_pick_tile(p.m, p.nout), vspw_stream(stream));
 }
 
 extern "C" int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, const float* wT, float* dx,
@@ -487,16 +537,14 @@ extern "C" int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, co
     p.m = (int)m;
     p.kdim = d->kh * d->kw * d->k;
     p.vec = (d->k % 4 == 0) ? 1 : 0;
-    int tiles = vspw_cdiv(p.m, BM) * vspw_cdiv(p.nout, BN);
-    hipLaunchKernelGGL(igemm_nt_kernel, dim3(tiles), dim3(256), 0, vspw_stream(stream), p);
-    return vspw_launch_status();
+    return launch_igemm_nt(p, nt_pick_tile(p.m, p.nout), vspw_stream(stream));
 }
 
 static void wgrad_plan(const vspw_conv_desc* d, int& splits, int& chunk) {
     long long P = (long long)d->n * d->oh * d->ow;
     int ncols = d->kh * d->kw * d->c;
     long long tiles = (long long)vspw_cdiv(d->k, BM) * vspw_cdiv(ncols, BN);
-    long long want = (1024 + tiles - 1) / tiles;
+    long long want = (1536 + tiles / 2) / tiles;
     long long max_splits = (P + 255) / 256;
     if (want > max_splits) want = max_splits;
     if (want < 1) want = 1;

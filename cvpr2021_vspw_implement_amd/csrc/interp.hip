@@ -98,6 +98,59 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float* __restri
     }
 }
 
+// Same adjoint for small source grids (the PPM branches: 1x1 ... 6x6 sources, 60x60 outputs): one workgroup per
+// (image, source pixel, 64-channel chunk); 16 float4 channel lanes x 16 footprint lanes, LDS reduction at the end.
+__global__ __launch_bounds__(256) void bilinear_bwd_block_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                 int ih, int iw, int oh, int ow, int c, int ldi, int ci,
+                                                                 int ldo, int co, float sy, float sx) {
+    __shared__ f32x4 red[16][16];
+    const int lc = threadIdx.x & 15, lp = threadIdx.x >> 4;
+    const int ch = (blockIdx.x * 16 + lc) * 4;
+    const int iy = blockIdx.y / iw, ix = blockIdx.y - iy * iw;
+    const int img = blockIdx.z;
+    const float ry = (float)oh / (float)ih, rx = (float)ow / (float)iw;
+    int oy_lo = (int)floorf(((float)iy - 1.f + 0.5f) * ry - 0.5f) - 1;
+    int oy_hi = (int)ceilf(((float)iy + 1.f + 0.5f) * ry - 0.5f) + 1;
+    int ox_lo = (int)floorf(((float)ix - 1.f + 0.5f) * rx - 0.5f) - 1;
+    int ox_hi = (int)ceilf(((float)ix + 1.f + 0.5f) * rx - 0.5f) + 1;
+    if (iy == 0) oy_lo = 0;
+    if (iy == ih - 1) oy_hi = oh - 1;
+    if (ix == 0) ox_lo = 0;
+    if (ix == iw - 1) ox_hi = ow - 1;
+    oy_lo = max(oy_lo, 0);
+    ox_lo = max(ox_lo, 0);
+    oy_hi = min(oy_hi, oh - 1);
+    ox_hi = min(ox_hi, ow - 1);
+    const int fw = ox_hi - ox_lo + 1, fh = oy_hi - oy_lo + 1;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (ch < c) {
+        for (int q = lp; q < fw * fh; q += 16) {
+            const int oy = oy_lo + q / fw, ox = ox_lo + q % fw;
+            int y0, y1, x0, x1;
+            float ly, lx;
+            bilinear_src(oy, sy, ih, y0, y1, ly);
+            float wy = 0.f;
+            if (y0 == iy) wy += 1.f - ly;
+            if (y1 == iy) wy += ly;
+            if (wy == 0.f) continue;
+            bilinear_src(ox, sx, iw, x0, x1, lx);
+            float wx = 0.f;
+            if (x0 == ix) wx += 1.f - lx;
+            if (x1 == ix) wx += lx;
+            if (wx == 0.f) continue;
+            acc += (wy * wx) * *reinterpret_cast<const f32x4*>(dy + (((size_t)img * oh + oy) * ow + ox) * ldo + co + ch);
+        }
+    }
+    red[lp][lc] = acc;
+    __syncthreads();
+    if (lp == 0 && ch < c) {
+        f32x4 a = red[0][lc];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) a += red[j][lc];
+        *reinterpret_cast<f32x4*>(dx + (((size_t)img * ih + iy) * iw + ix) * ldi + ci + ch) = a;
+    }
+}
+
 template <bool ADD>
 __global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                             long long rows, int c, int lds, int sco, int ldd, int dco) {
@@ -137,6 +190,14 @@ extern "C" int vspw_bilinear_bwd(const float* dy, float* dx, int n, int ih, int 
                                  int ci, int ldo, int co, void* stream) {
     if (!dy || !dx || n <= 0 || ih <= 0 || iw <= 0 || oh <= 0 || ow <= 0 || c <= 0) return VSPW_EINVAL;
     if (ci < 0 || co < 0 || ci + c > ldi || co + c > ldo) return VSPW_EINVAL;
+    const bool vec = (c % 4 == 0) && (ldi % 4 == 0) && (ci % 4 == 0) && (ldo % 4 == 0) && (co % 4 == 0);
+    const long long footprint = ((long long)oh * ow) / ((long long)ih * iw);
+    if (vec && footprint >= 16 && n <= 65535 && (long long)ih * iw <= 65535) {
+        dim3 grid(vspw_cdiv(c, 64), ih * iw, n);
+        hipLaunchKernelGGL(bilinear_bwd_block_kernel, grid, dim3(256), 0, vspw_stream(stream), dy, dx, ih, iw, oh, ow,
+                           c, ldi, ci, ldo, co, (float)ih / (float)oh, (float)iw / (float)ow);
+        return vspw_launch_status();
+    }
     long long total = (long long)n * ih * iw * c;
     hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream), dy,
                        dx, n, ih, iw, oh, ow, c, ldi, ci, ldo, co, (float)ih / (float)oh, (float)iw / (float)ow);

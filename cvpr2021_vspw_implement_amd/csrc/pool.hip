@@ -154,6 +154,51 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const float* 
     }
 }
 
+// Fused adjoint of the whole pyramid: dx = sum over up to 4 scales of the adaptive-pool adjoint, optionally composed with
+// the temporal-mean adjoint (T > 1: dy_i is the gradient of the BLENDED [B][s][s][c] tensor and every frame t of clip b
+// receives dy_i[b]/T).  One pass over dx instead of one per scale.
+struct PoolBwdMulti {
+    const float* dy[4];
+    int s[4];
+    int ns;
+};
+
+__global__ __launch_bounds__(256) void adaptive_avgpool_bwd_multi_kernel(PoolBwdMulti p, float* __restrict__ dx, int n,
+                                                                         int h, int w, int c, int T, int B) {
+    const int cw = c / 4;
+    const long long total = (long long)n * h * w * cw;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float invT = 1.f / (float)T;
+    for (; i < total; i += stride) {
+        const int ch = (int)(i % cw) * 4;
+        long long r = i / cw;
+        const int ix = (int)(r % w);
+        r /= w;
+        const int iy = (int)(r % h);
+        const int img = (int)(r / h);
+        const int src = (T > 1) ? (img % B) : img;
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < p.ns; ++k) {
+            const int s = p.s[k];
+            const int byc = (int)(((long long)iy * s) / h);
+            const int bxc = (int)(((long long)ix * s) / w);
+            for (int by = max(0, byc - 1); by <= min(s - 1, byc + 1); ++by) {
+                const int y0 = bin_start(by, h, s), y1 = bin_end(by, h, s);
+                if (iy < y0 || iy >= y1) continue;
+                for (int bx = max(0, bxc - 1); bx <= min(s - 1, bxc + 1); ++bx) {
+                    const int x0 = bin_start(bx, w, s), x1 = bin_end(bx, w, s);
+                    if (ix < x0 || ix >= x1) continue;
+                    const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+                    g += inv * *reinterpret_cast<const f32x4*>(p.dy[k] + (((size_t)src * s + by) * s + bx) * c + ch);
+                }
+            }
+        }
+        if (T > 1) g *= invT;
+        *reinterpret_cast<f32x4*>(dx + (size_t)i * 4) = g;
+    }
+}
+
 // ---- temporal mean ---------------------------------------------------------------------------------
 // x is [T][B][inner] (frames stacked frame-major along the batch, as torch.cat(clip_imgs) makes them).
 // The reference concatenates [current, others...] and takes torch.mean over that axis; fp32 summation order
@@ -229,6 +274,24 @@ extern "C" int vspw_adaptive_avgpool_bwd(const float* dy, float* dx, int n, int 
     long long total = (long long)n * h * w * c;
     hipLaunchKernelGGL(adaptive_avgpool_bwd_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0,
                        vspw_stream(stream), dy, dx, n, h, w, c, s, accumulate);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_pyramid_pool_bwd(const float* const* dy, const int* scales, int nscales, float* dx, int n, int h,
+                                     int w, int c, int T, void* stream) {
+    if (!dy || !scales || !dx || nscales <= 0 || nscales > 4 || n <= 0 || h <= 0 || w <= 0 || c <= 0 || T <= 0)
+        return VSPW_EINVAL;
+    if (c % 4 != 0 || n % T != 0) return VSPW_EINVAL;
+    PoolBwdMulti p;
+    p.ns = nscales;
+    for (int k = 0; k < 4; ++k) {
+        p.dy[k] = k < nscales ? dy[k] : nullptr;
+        p.s[k] = k < nscales ? scales[k] : 1;
+        if (k < nscales && (!dy[k] || scales[k] <= 0)) return VSPW_EINVAL;
+    }
+    long long total = (long long)n * h * w * (c / 4);
+    hipLaunchKernelGGL(adaptive_avgpool_bwd_multi_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0,
+                       vspw_stream(stream), p, dx, n, h, w, c, T, n / T);
     return vspw_launch_status();
 }
 

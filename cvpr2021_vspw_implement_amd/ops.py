@@ -80,12 +80,12 @@ def kernel_timer(enable):
 def kernel_timer_records():
     """[(kernel name, algorithmic flops, ms)] for every timed launch (synchronises)."""
     torch.cuda.synchronize()
-    return [(n, f, e0.elapsed_time(e1)) for n, f, e0, e1 in _ktimer["records"]]
+    return [(n, f, e0.elapsed_time(e1), tag) for n, f, e0, e1, tag in _ktimer["records"]]
 
 
 class _Timed:
-    def __init__(self, name, flops):
-        self.name, self.flops = name, flops
+    def __init__(self, name, flops, tag=None):
+        self.name, self.flops, self.tag = name, flops, tag
 
     def __enter__(self):
         if _ktimer["on"]:
@@ -97,12 +97,16 @@ class _Timed:
     def __exit__(self, *a):
         if _ktimer["on"]:
             self.e1.record()
-            _ktimer["records"].append((self.name, self.flops, self.e0, self.e1))
+            _ktimer["records"].append((self.name, self.flops, self.e0, self.e1, self.tag))
         return False
 
 
 def _conv_flops(d):
     return 2.0 * d.n * d.oh * d.ow * d.k * d.kh * d.kw * d.c
+
+
+def _conv_tag(d, what):
+    return "%s n%d %dx%d c%d->k%d %dx%d s%d d%d" % (what, d.n, d.h, d.w, d.c, d.k, d.kh, d.kw, d.stride, d.dil)
 
 
 def _ws(nbytes, device):
@@ -125,7 +129,7 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False):
     if want_stats:
         tiles = _C.query("vspw_conv2d_stats_partials", ctypes.byref(d))
         part = torch.empty((tiles, 2, k), device=x.device, dtype=torch.float32)
-    with _Timed("igemm_nt_kernel", _conv_flops(d)):
+    with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "fwd")):
         _C.call("vspw_conv2d_fwd", ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y), _p(part), _stream())
     return y, part, d
 
@@ -135,7 +139,7 @@ def conv2d_backward_data(dy, w, d):
     wT = torch.empty((c, kh, kw, k), device=w.device, dtype=torch.float32)
     _C.call("vspw_weight_transpose", _p(w), _p(wT), k, kh * kw, c, _stream())
     dx = empty_nhwc(d.n, d.c, d.h, d.w, dy.device)
-    with _Timed("igemm_nt_kernel", _conv_flops(d)):
+    with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "dgrad")):
         _C.call("vspw_conv2d_bwd_data", ctypes.byref(d), _p(dy), _p(wT), _p(dx), _stream())
     return dx
 
@@ -144,7 +148,7 @@ def conv2d_backward_weight(dy, x, d):
     dw = torch.empty((d.k, d.kh, d.kw, d.c), device=dy.device, dtype=torch.float32).permute(0, 3, 1, 2)
     nbytes = _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d))
     ws = _ws(nbytes, dy.device) if nbytes else None
-    with _Timed("igemm_tn_kernel", _conv_flops(d)):
+    with _Timed("igemm_tn_kernel", _conv_flops(d), _conv_tag(d, "wgrad")):
         _C.call("vspw_conv2d_bwd_weight", ctypes.byref(d), _p(dy), _p(x), _p(dw), _p(ws), nbytes, _stream())
     return dw
 
@@ -469,11 +473,16 @@ class PyramidPoolFn(torch.autograd.Function):
         st = _stream()
         dev = grads[0].device
         dx = empty_nhwc(n, c, h, w, dev)
+        live = [(s, to_nhwc(g)) for s, g in zip(scales, grads) if g is not None]
+        if not live:
+            return dx.zero_(), None, None, None
+        if wts is None and c % 4 == 0 and len(live) <= 4:  # one fused pass: all scales + the temporal-mean adjoint
+            ptrs = (ctypes.c_void_p * len(live))(*[g.data_ptr() for _, g in live])
+            svec = (ctypes.c_int * len(live))(*[s for s, _ in live])
+            _C.call("vspw_pyramid_pool_bwd", ptrs, svec, len(live), _p(dx), n, h, w, c, T, st)
+            return dx, None, None, None
         first = True
-        for s, g in zip(scales, grads):
-            if g is None:
-                continue
-            g = to_nhwc(g)
+        for s, g in live:
             if T > 1:
                 gp = empty_nhwc(n, c, s, s, dev)
                 _C.call("vspw_temporal_mean_bwd", _p(g), _p(wts), _p(gp), T, B, s * s * c, st)
@@ -481,8 +490,6 @@ class PyramidPoolFn(torch.autograd.Function):
                 gp = g
             _C.call("vspw_adaptive_avgpool_bwd", _p(gp), _p(dx), n, h, w, c, s, 0 if first else 1, st)
             first = False
-        if first:
-            dx.zero_()
         return dx, None, None, None
 
 

@@ -105,6 +105,11 @@ int vspw_adaptive_avgpool_fwd(const float* x, float* y, int n, int h, int w, int
 /* dx (+)= adjoint; accumulate != 0 adds into dx. */
 int vspw_adaptive_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int s, int accumulate,
                               void* stream);
+/* Fused adjoint of the PPM pyramid: dx = sum_k adaptive_avgpool_bwd(dy[k], scales[k]) in one pass; with T > 1 each
+ * dy[k] is the gradient of the temporally BLENDED [n/T][s][s][c] tensor (uniform weights) and the temporal-mean
+ * adjoint (x 1/T to every frame of the clip) is folded in.  dy / scales are HOST arrays of nscales (<= 4) entries. */
+int vspw_pyramid_pool_bwd(const float* const* dy, const int* scales, int nscales, float* dx, int n, int h, int w,
+                          int c, int T, void* stream);
 /* Temporal Context Blending of TCB-PSP (models/clip_psp.py:181-188): frames are stacked frame-major along the
  * batch ([t][b]); y[b] = (1/T) sum_t x[t*B + b] * (wts ? wts[b*T + t] : 1). `inner` = elements per image. */
 int vspw_temporal_mean_fwd(const float* x, const float* wts, float* y, int T, int B, long long inner, void* stream);

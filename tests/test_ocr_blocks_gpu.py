@@ -125,9 +125,10 @@ def test_spatial_ocr_module(dev, training, dims):
 
     assert rel(xd.grad, xr.grad) < gtol and rel(pd.grad, pr.grad) < gtol
     bad = []
+    gmax = max(v.grad.norm().item() for v in params.values())
     for k, p in mod.named_parameters():
         b = params[k].grad
-        if b.norm().item() < 1e-5:  # conv biases in front of a train-mode BN have an identically-zero gradient
+        if b.norm().item() < 1e-4 * gmax:  # conv biases in front of a train-mode BN: exact gradient is zero
             continue
         if rel(p.grad, b) > gtol:
             bad.append((k, rel(p.grad, b)))

@@ -273,6 +273,215 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// v2 of the NT kernel for the vector path (C % 4 == 0, 32-bit offsets, forward or stride-1 data gradient):
+//   * two LDS buffers, ONE barrier per K-tile (tile k+1 is written to the other buffer while tile k is consumed);
+//   * the global loads of tile k+2 are issued piecewise between the four MFMA chunks of tile k and the whole loop body
+//     is straight-line (clamped always-valid addresses + select instead of branches), so the address arithmetic,
+//     ds_writes and ds_reads issue in the shadow of the 64-cycle fp32 MFMAs instead of in front of them;
+//   * (tap, channel) of a thread's k-column advance incrementally: no integer division in the loop.
+// MODE 0: forward gather (any stride);  MODE 1: data-gradient gather, stride 1.
+template <int WM, int WN, int MODE>
+__global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
+    constexpr int TM = 64 * WM, TN = 64 * WN;
+    constexpr int RA = TM / 32, RB = TN / 32;
+    __shared__ __attribute__((aligned(16))) float As[2][TM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TN * LDA];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int tiles_n = (p.nout + TN - 1) / TN;
+    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_n = vb % tiles_n;
+    const int tile_m = vb / tiles_n;
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
+
+    const int lrow = tid >> 3;
+    const int lcol = (tid & 7) * 4;
+
+    int a_base[RA], a_by[RA], a_bx[RA];
+    bool a_ok[RA];
+    const int ohw = p.oh * p.ow;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        a_ok[i] = m < p.m;
+        const int mm = a_ok[i] ? m : 0;
+        const int n = mm / ohw;
+        const int r = mm - n * ohw;
+        const int oy = r / p.ow;
+        const int ox = r - oy * p.ow;
+        a_base[i] = n * p.h;
+        if (MODE == 0) {
+            a_by[i] = oy * p.stride - p.pad;
+            a_bx[i] = ox * p.stride - p.pad;
+        } else {
+            a_by[i] = oy + p.pad;
+            a_bx[i] = ox + p.pad;
+        }
+    }
+    bool b_ok[RB];
+    int b_off[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + lrow + 32 * i;
+        b_ok[i] = n < p.nout;
+        b_off[i] = (b_ok[i] ? n : 0) * p.kdim;
+    }
+
+    // this thread's k-column state: k4 = kt*32 + lcol -> (ky, kx, ci)
+    int k4 = lcol;
+    int ci, ky, kx;
+    {
+        const int tap = k4 / p.c;
+        ci = k4 - tap * p.c;
+        ky = tap / p.kw;
+        kx = tap - ky * p.kw;
+    }
+    // c >= BK on this path (host check), so a +32 step crosses at most one tap boundary: branch-free update
+    auto advance = [&]() {
+        k4 += BK;
+        ci += BK;
+        const bool wrap = ci >= p.c;
+        ci = wrap ? ci - p.c : ci;
+        kx = wrap ? kx + 1 : kx;
+        const bool wrapx = kx == p.kw;
+        kx = wrapx ? 0 : kx;
+        ky = wrapx ? ky + 1 : ky;
+    };
+    const int sgn = (MODE == 0) ? p.dil : -p.dil;
+    // Loads always use a clamped, valid address; the zeroing of out-of-image / past-K taps is a select applied when
+    // the registers are written to LDS (one K-tile later), so no vmcnt wait is forced near the load.
+    f32x4 ra[RA], rb[RB];
+    bool oka[RA], okb[RB];
+    auto load_a = [&](int i) {
+        const bool kin = k4 < p.kdim;
+        const int sy = a_by[i] + sgn * ky;
+        const int sx = a_bx[i] + sgn * kx;
+        oka[i] = kin & a_ok[i] & ((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w);
+        const int syc = min(max(sy, 0), p.h - 1), sxc = min(max(sx, 0), p.w - 1);
+        const int off = ((a_base[i] + syc) * p.w + sxc) * p.c + (kin ? ci : 0);
+        ra[i] = *reinterpret_cast<const f32x4*>(p.src + off);
+    };
+    auto load_b = [&](int i) {
+        okb[i] = (k4 < p.kdim) & b_ok[i];
+        rb[i] = *reinterpret_cast<const f32x4*>(p.wt + (okb[i] ? b_off[i] + k4 : 0));
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto store_tile = [&](float* Ad, float* Bd) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i)
+            *reinterpret_cast<f32x4*>(&Ad[(lrow + 32 * i) * LDA + lcol]) = oka[i] ? ra[i] : zero4;
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            *reinterpret_cast<f32x4*>(&Bd[(lrow + 32 * i) * LDA + lcol]) = okb[i] ? rb[i] : zero4;
+    };
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) load_a(i);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) load_b(i);
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.kdim + BK - 1) / BK;
+    // prologue: tile 0 -> LDS[0]; tile 1 -> registers
+    load_tile();
+    store_tile(As[0], Bs[0]);
+    advance();  // state now describes tile 1 (loads past kdim are zeroed at store time)
+    load_tile();
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const float* Ac = As[cur];
+        const float* Bc = Bs[cur];
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+            f32x4 a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+                a[i] = *reinterpret_cast<const f32x4*>(&Ac[(wm * 32 * WM + i * 32 + l31) * LDA + kc * 8 + 4 * lh]);
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                b[j] = *reinterpret_cast<const f32x4*>(&Bc[(wn * 32 * WN + j * 32 + l31) * LDA + kc * 8 + 4 * lh]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+            if (kc == 0) {
+                // tile kt+1 has been in flight since the middle of the previous iteration: registers -> the other
+                // LDS buffer (its last readers passed the barrier that ended iteration kt-1), then reuse the
+                // registers for tile kt+2, which gets a whole iteration to land.
+                store_tile(As[cur ^ 1], Bs[cur ^ 1]);
+                advance();
+                load_tile();
+            }
+        }
+        __syncthreads();
+    }
+
+    float csum[WN], csq[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        csum[j] = 0.f;
+        csq[j] = 0.f;
+        const int col = n0 + wn * 32 * WN + j * 32 + l31;
+        const bool cok = col < p.nout;
+        const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (cok && row < p.m) {
+                    float v = acc[i][j][r] + bv;
+                    p.dst[(size_t)row * p.ldd + col] = v;
+                    csum[j] += v;
+                    csq[j] += v * v;
+                }
+            }
+        }
+    }
+    if (p.stat_part != nullptr) {
+        float* red = As[0];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            float s = csum[j] + __shfl_xor(csum[j], 32, 64);
+            float q = csq[j] + __shfl_xor(csq[j], 32, 64);
+            if (lh == 0) {
+                int c = wn * 32 * WN + j * 32 + l31;
+                red[(0 * 2 + wm) * TN + c] = s;
+                red[(1 * 2 + wm) * TN + c] = q;
+            }
+        }
+        __syncthreads();
+        if (tid < TN) {
+            int col = n0 + tid;
+            if (col < p.nout) {
+                float* out = p.stat_part + (size_t)tile_m * 2 * p.nout;
+                out[col] = red[0 * TN + tid] + red[1 * TN + tid];
+                out[p.nout + col] = red[2 * TN + tid] + red[3 * TN + tid];
+            }
+        }
+    }
+}
+
 // Tile choice: fp32 MFMA work is uniform per tile, so the only scheduling loss is the tail; prefer the big tile
 // (fewest LDS/global bytes per FLOP) when it still yields >= 4 workgroups per CU, otherwise halve the tile.
 static int nt_pick_tile(long long m, int nout) {
@@ -285,7 +494,34 @@ static int nt_pick_tile(long long m, int nout) {
 
 static int nt_tile_rows(int cfg) { return cfg == 22 ? 128 : 64; }
 
+template <int MODE>
+static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
+    if (cfg == 22) {
+        int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, MODE>), dim3(tiles), dim3(256), 0, st, p);
+    } else if (cfg == 12) {
+        int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 2, MODE>), dim3(tiles), dim3(256), 0, st, p);
+    } else {
+        int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 1, MODE>), dim3(tiles), dim3(256), 0, st, p);
+    }
+}
+
 static int launch_igemm_nt(const IgemmNT& p, int cfg, hipStream_t st) {
+    const long long src_elems = (long long)p.nb * p.h * p.w * p.c;
+    const long long wt_elems = (long long)p.nout * p.kdim;
+    // measured (profiles/r01_c_kernel_report.csv): v2 wins 5-12 % on the 128x128 tile; on the 64-row tiles its two LDS
+    // buffers cap residency at 2 workgroups/CU and the single-buffer kernel (4/CU) is faster
+    const bool v2 = cfg == 22 && p.vec && p.c >= BK && src_elems < 0x7fffffffLL && wt_elems < 0x7fffffffLL &&
+                    (p.mode == 0 || p.stride == 1);
+    if (v2) {
+        if (p.mode == 0)
+            launch_nt_v2<0>(p, cfg, st);
+        else
+            launch_nt_v2<1>(p, cfg, st);
+        return vspw_launch_status();
+    }
     if (cfg == 22) {
         int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
         hipLaunchKernelGGL((igemm_nt_kernel<2, 2>), dim3(tiles), dim3(256), 0, st, p);

@@ -485,14 +485,13 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
 // Tile choice: fp32 MFMA work is uniform per tile, so the only scheduling loss is the tail; prefer the big tile
 // (fewest LDS/global bytes per FLOP) when it still yields >= 4 workgroups per CU, otherwise halve the tile.
 static int nt_pick_tile(long long m, int nout) {
+    if (nout <= 64) return (((m + 127) / 128) >= 1024) ? 21 : 11;  // narrow outputs (stem): 128x64 tile when M is large
     const long long b22 = ((m + 127) / 128) * ((nout + 127) / 128);
     if (b22 >= 1024) return 22;
-    const long long b12 = ((m + 63) / 64) * ((nout + 127) / 128);
-    if (b12 >= 1024 || nout > 64) return 12;
-    return 11;
+    return 12;
 }
 
-static int nt_tile_rows(int cfg) { return cfg == 22 ? 128 : 64; }
+static int nt_tile_rows(int cfg) { return (cfg == 22 || cfg == 21) ? 128 : 64; }
 
 template <int MODE>
 static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
@@ -528,6 +527,9 @@ static int launch_igemm_nt(const IgemmNT& p, int cfg, hipStream_t st) {
     } else if (cfg == 12) {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
         hipLaunchKernelGGL((igemm_nt_kernel<1, 2>), dim3(tiles), dim3(256), 0, st, p);
+    } else if (cfg == 21) {
+        int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);
+        hipLaunchKernelGGL((igemm_nt_kernel<2, 1>), dim3(tiles), dim3(256), 0, st, p);
     } else {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
         hipLaunchKernelGGL((igemm_nt_kernel<1, 1>), dim3(tiles), dim3(256), 0, st, p);
@@ -684,6 +686,133 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(IgemmTN p) {
     }
 }
 
+// v2 of the TN kernel for the vector path (Cout % 4 == 0, Cin % 4 == 0, 32-bit offsets): same pipeline as
+// igemm_nt_v2_kernel — two LDS buffers, one barrier per 32-pixel K-tile, straight-line loop body with clamped
+// always-valid addresses (zeroing applied when the registers are written to LDS), next-next tile's global loads issued
+// in the shadow of the MFMAs.
+__global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    const int tiles_n = (p.ncols + BN - 1) / BN;
+    const int tile_n = blockIdx.x % tiles_n;
+    const int tile_m = blockIdx.x / tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.y;
+    const int p_begin = split * p.chunk;
+    const int p_end = min(p.P, p_begin + p.chunk);
+
+    const int krow = tid >> 5;
+    const int c4 = (tid & 31) * 4;
+
+    // this thread's A column (co) and B column (tap, ci): fixed for the whole kernel
+    const int co = m0 + c4;
+    const bool a_colok = co < p.k;
+    const int ncol = n0 + c4;
+    const bool b_colok = ncol < p.ncols;
+    int b_ci, b_dy, b_dx;
+    {
+        const int nn = b_colok ? ncol : 0;
+        const int tap = nn / p.c;
+        b_ci = nn - tap * p.c;
+        const int ky = tap / p.kw;
+        const int kx = tap - ky * p.kw;
+        b_dy = ky * p.dil - p.pad;
+        b_dx = kx * p.dil - p.pad;
+    }
+    const int ohw = p.oh * p.ow;
+
+    f32x4 ra[4], rb[4];
+    bool oka[4], okb[4];
+    auto load_tile = [&](int pk0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pp = pk0 + krow + 8 * i;
+            const bool pin = pp < p_end;
+            const int pc = pin ? pp : p_begin;
+            oka[i] = pin & a_colok;
+            ra[i] = *reinterpret_cast<const f32x4*>(p.dy + (pc * p.k + (a_colok ? co : 0)));
+            const int n = pc / ohw;
+            const int r = pc - n * ohw;
+            const int oy = r / p.ow;
+            const int ox = r - oy * p.ow;
+            const int sy = oy * p.stride + b_dy, sx = ox * p.stride + b_dx;
+            okb[i] = pin & b_colok & ((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w);
+            const int syc = min(max(sy, 0), p.h - 1), sxc = min(max(sx, 0), p.w - 1);
+            rb[i] = *reinterpret_cast<const f32x4*>(p.x + (((n * p.h + syc) * p.w + sxc) * p.c + b_ci));
+        }
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto store_tile = [&](float* Ad, float* Bd) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(&Ad[(krow + 8 * i) * BM + c4]) = oka[i] ? ra[i] : zero4;
+            *reinterpret_cast<f32x4*>(&Bd[(krow + 8 * i) * BN + c4]) = okb[i] ? rb[i] : zero4;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p_end - p_begin + BK - 1) / BK;
+    if (nk > 0) {
+        load_tile(p_begin);
+        store_tile(As[0], Bs[0]);
+        load_tile(p_begin + BK);  // rows past p_end are zeroed at store time
+        __syncthreads();
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const float* Ac = As[cur];
+        const float* Bc = Bs[cur];
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = Ac[(2 * s + lh) * BM + wm * 64 + i * 32 + l31];
+                b[i] = Bc[(2 * s + lh) * BN + wn * 64 + i * 32 + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            if (s == 3) {
+                store_tile(As[cur ^ 1], Bs[cur ^ 1]);        // tile kt+1 (in flight since the previous iteration)
+                load_tile(p_begin + (kt + 2) * BK);          // tile kt+2 gets a whole iteration to land
+            }
+        }
+        __syncthreads();
+    }
+
+    float* out = p.part + (size_t)split * p.k * p.ncols;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        if (col >= p.ncols) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < p.k) out[(size_t)row * p.ncols + col] = acc[i][j][r];
+            }
+        }
+    }
+}
+
 __global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long long n, int splits) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -780,7 +909,7 @@ static void wgrad_plan(const vspw_conv_desc* d, int& splits, int& chunk) {
     long long P = (long long)d->n * d->oh * d->ow;
     int ncols = d->kh * d->kw * d->c;
     long long tiles = (long long)vspw_cdiv(d->k, BM) * vspw_cdiv(ncols, BN);
-    long long want = (1536 + tiles / 2) / tiles;
+    long long want = (1024 + tiles / 2) / tiles;  // ~4 workgroups per CU (2 resident) keeps the tail short
     long long max_splits = (P + 255) / 256;
     if (want > max_splits) want = max_splits;
     if (want < 1) want = 1;
@@ -821,7 +950,12 @@ extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, 
     p.vec_a = (d->k % 4 == 0) ? 1 : 0;
     p.vec_b = (d->c % 4 == 0) ? 1 : 0;
     int tiles = vspw_cdiv(p.k, BM) * vspw_cdiv(p.ncols, BN);
-    hipLaunchKernelGGL(igemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
+    const bool v2 = p.vec_a && p.vec_b && (long long)p.P * p.k < 0x7fffffffLL &&
+                    (long long)d->n * d->h * d->w * d->c < 0x7fffffffLL;
+    if (v2)
+        hipLaunchKernelGGL(igemm_tn_v2_kernel, dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
+    else
+        hipLaunchKernelGGL(igemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
     int st = vspw_launch_status();
     if (st != VSPW_OK) return st;
     if (splits > 1) {

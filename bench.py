@@ -104,7 +104,10 @@ def main():
     cls = M.Clip_PSP if args.method == "clip_psp" else M.ClipOCRNet
     net = cls(enc, crit, margs, deep_sup_scale=0.4).to(dev)
     net.train()
-    model = vdist.DataParallelOverRCCL(net)  # param broadcast, bucketed grad all-reduce, SyncBN over RCCL (N>1)
+    # param broadcast, bucketed grad all-reduce, SyncBN over RCCL (N>1); VSPW_FORCE_COLLECTIVES=1 runs the same
+    # collectives in a 1-rank RCCL group (the only way to exercise them on a single-GPU box)
+    force = os.environ.get("VSPW_FORCE_COLLECTIVES") == "1"
+    model = vdist.DataParallelOverRCCL(net, force_collectives=force)
     opt = optim.create_optimizers(net, lr=0.002, weight_decay=1e-4, momentum=0.9)
     imgs, labs = make_inputs(dev, 304 + rank)
     max_iters = 1000
@@ -190,7 +193,7 @@ def main():
                        if args.method == "clip_psp" else
                        "TCB-OCR (ClipOCRNet, resnet101dilated) train step: T=5, B=2/GPU, 479x479, 124 classes",
                        "global_batch_clips": world * B_CLIPS, "frames_per_step_per_gpu": T_FRAMES * B_CLIPS,
-                       "parallelism": "dp%d" % world, "sync_bn": world > 1},
+                       "parallelism": "dp%d" % world, "sync_bn": world > 1 or force},
             "e2e_mfma_frac": round(GFLOP_PER_CLIP * 1e9 * clips_per_s / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
             "last_loss": round(last_loss, 5),
             "roofline": roofline,
@@ -198,7 +201,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

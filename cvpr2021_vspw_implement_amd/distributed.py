@@ -22,7 +22,7 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("VSPW_FORCE_COLLECTIVES") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -40,9 +40,10 @@ def init_from_env(backend=None):
 class GradReducer:
     """Bucketed, backward-overlapped gradient averaging for any nn.Module (device-agnostic host logic)."""
 
-    def __init__(self, module, bucket_mb=25.0, group=None):
+    def __init__(self, module, bucket_mb=25.0, group=None, force=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         params = [p for p in module.parameters() if p.requires_grad]
         seen, uniq = set(), []
         for p in params:
@@ -75,12 +76,12 @@ class GradReducer:
         self.pending = [len(b) for b in self.buckets]
         self.handles = [None] * len(self.buckets)
         self.hooks = []
-        if self.world > 1:
+        if self.active:
             for p in uniq:
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def broadcast_parameters(self, module, src=0):
-        if self.world <= 1:
+        if not self.active:
             return
         for t in list(module.parameters()) + list(module.buffers()):
             if t.is_floating_point() or t.dtype == torch.long:
@@ -95,7 +96,7 @@ class GradReducer:
 
     def wait(self):
         """Finish the outstanding all-reduces and write the averaged gradients back. Call before optimizer.step()."""
-        if self.world <= 1:
+        if not self.active:
             return
         inv = 1.0 / self.world
         for bi, bucket in enumerate(self.buckets):
@@ -118,12 +119,12 @@ class DataParallelOverRCCL(torch.nn.Module):
     """Drop-in for `nn.DataParallel(module)` + `patch_replication_callback` in the clip drivers: same call
     signature (`module(feed_dict)` -> (loss, acc)), one process per GPU underneath."""
 
-    def __init__(self, module, bucket_mb=25.0, sync_bn=True):
+    def __init__(self, module, bucket_mb=25.0, sync_bn=True, force_collectives=False):
         super().__init__()
         self.module = module
-        self.reducer = GradReducer(module, bucket_mb)
+        self.reducer = GradReducer(module, bucket_mb, force=force_collectives)
         self.reducer.broadcast_parameters(module)
-        ops.set_sync_bn(sync_bn and self.reducer.world > 1)
+        ops.set_sync_bn(sync_bn and self.reducer.active, force=force_collectives)
 
     def forward(self, *a, **k):
         return self.module(*a, **k)

@@ -195,24 +195,28 @@ def conv2d(x, w, bias=None, stride=1, pad=0, dil=1):
 
 
 # --------------------------------------------------------------------------------------------------- batch norm
-_sync_group = {"enabled": False, "group": None}
+_sync_group = {"enabled": False, "group": None, "force": False}
 
 
-def set_sync_bn(enabled, group=None):
+def set_sync_bn(enabled, group=None, force=False):
     """Enable the cross-rank exchange of BatchNorm statistics (SynchronizedBatchNorm semantics,
-    models/sync_batchnorm/batchnorm.py:110-150) over torch.distributed (RCCL on ROCm)."""
+    models/sync_batchnorm/batchnorm.py:110-150) over torch.distributed (RCCL on ROCm).
+    `force` issues the collectives even in a 1-rank group (exercises the RCCL path on a single-GPU box)."""
     _sync_group["enabled"] = bool(enabled)
     _sync_group["group"] = group
+    _sync_group["force"] = bool(force)
 
 
 def _sync_world():
+    """Number of ranks whose statistics are combined; 0 means 'one rank, but run the collectives anyway'."""
     if not _sync_group["enabled"]:
         return 1
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()):
         return 1
-    return dist.get_world_size(_sync_group["group"])
+    w = dist.get_world_size(_sync_group["group"])
+    return 0 if (w == 1 and _sync_group["force"]) else w
 
 
 def _all_reduce_sums(sums):
@@ -238,7 +242,7 @@ class BatchNormActFn(torch.autograd.Function):
         count = float(rows)
         world = 1
         if training:
-            if rows * _sync_world() <= 1:
+            if rows * max(_sync_world(), 1) <= 1:
                 raise ValueError("Expected more than 1 value per channel when training, got input size %s"
                                  % (tuple(x.shape),))
             sums = torch.empty((2, c), device=dev, dtype=torch.float64)
@@ -249,9 +253,9 @@ class BatchNormActFn(torch.autograd.Function):
                 ws = _ws(nbytes, dev)
                 _C.call("vspw_bn_stats", _p(x), rows, c, _p(sums), _p(ws), nbytes, st)
             world = _sync_world()
-            if world > 1:
+            if world != 1:
                 _all_reduce_sums(sums)
-                count = float(rows * world)
+                count = float(rows * max(world, 1))
             _C.call("vspw_bn_finalize", _p(sums), ctypes.c_double(count), _p(gamma), _p(beta), _p(running_mean),
                     _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), c, st)
         else:
@@ -291,7 +295,7 @@ class BatchNormActFn(torch.autograd.Function):
             _C.call("vspw_bn_bwd_apply", _p(dz), _p(z), _p(x), _p(mean), _p(invstd), _p(gamma), _p(sums),
                     ctypes.c_double(ctx.count), _p(mask), rows, c, h * w, relu, 1 if ctx.training else 0, None, None,
                     _p(dgamma), _p(dbeta), st)
-        if ctx.training and ctx.world > 1:
+        if ctx.training and ctx.world != 1:
             _all_reduce_sums(sums)
         dx = empty_nhwc(n, c, h, w, dev) if ctx.needs_input_grad[0] else None
         dres = empty_nhwc(n, c, h, w, dev) if (ctx.has_res and ctx.needs_input_grad[5]) else None
@@ -317,7 +321,7 @@ class ConvBNActFn(torch.autograd.Function):
                 momentum, eps, relu):
         _require_gpu(x, "conv_bn_act")
         x = to_nhwc(x)
-        fuse_stats = training and _sync_world() == 1
+        fuse_stats = training
         y, part, d = conv2d_forward(x, w, cbias, stride, pad, dil, want_stats=fuse_stats)
         n, c, h, wd = y.shape
         rows = n * h * wd
@@ -328,7 +332,7 @@ class ConvBNActFn(torch.autograd.Function):
         count = float(rows)
         world = 1
         if training:
-            if rows * _sync_world() <= 1:
+            if rows * max(_sync_world(), 1) <= 1:
                 raise ValueError("Expected more than 1 value per channel when training, got input size %s"
                                  % (tuple(y.shape),))
             sums = torch.empty((2, c), device=dev, dtype=torch.float64)
@@ -339,9 +343,9 @@ class ConvBNActFn(torch.autograd.Function):
                 ws = _ws(nbytes, dev)
                 _C.call("vspw_bn_stats", _p(y), rows, c, _p(sums), _p(ws), nbytes, st)
             world = _sync_world()
-            if world > 1:
+            if world != 1:
                 _all_reduce_sums(sums)
-                count = float(rows * world)
+                count = float(rows * max(world, 1))
             _C.call("vspw_bn_finalize", _p(sums), ctypes.c_double(count), _p(gamma), _p(beta), _p(running_mean),
                     _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), c, st)
         else:
@@ -385,7 +389,7 @@ class ConvBNActFn(torch.autograd.Function):
             _C.call("vspw_bn_bwd_apply", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums),
                     ctypes.c_double(ctx.count), _p(mask), rows, c, h * wd, relu, train, None, None, _p(dgamma),
                     _p(dbeta), st)
-        if ctx.training and ctx.world > 1:
+        if ctx.training and ctx.world != 1:
             _all_reduce_sums(sums)
         dy = empty_nhwc(n, c, h, wd, dev)
         dres = empty_nhwc(n, c, h, wd, dev) if (ctx.has_res and ctx.needs_input_grad[7]) else None

@@ -295,6 +295,35 @@ extern "C" int vspw_pyramid_pool_bwd(const float* const* dy, const int* scales, 
     return vspw_launch_status();
 }
 
+// dwts[b][j] = (1/T) * sum_i dy[b][i] * x[t(j)][b][i]   (gradient of the psp_weight temporal softmax weights)
+__global__ __launch_bounds__(256) void temporal_mean_wgrad_kernel(const float* __restrict__ dy,
+                                                                  const float* __restrict__ x,
+                                                                  float* __restrict__ dw, int T, int B, long long inner,
+                                                                  int accumulate) {
+    __shared__ double red[4];
+    const int b = blockIdx.x / T, j = blockIdx.x % T;
+    const int t = (j == 0) ? (T - 1) : (j - 1);
+    const float* px = x + ((size_t)t * B + b) * inner;
+    const float* pg = dy + (size_t)b * inner;
+    double s = 0;
+    for (long long i = threadIdx.x; i < inner; i += blockDim.x) s += (double)pg[i] * (double)px[i];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (float)((red[0] + red[1] + red[2] + red[3]) / (double)T);
+        dw[blockIdx.x] = accumulate ? dw[blockIdx.x] + v : v;
+    }
+}
+
+extern "C" int vspw_temporal_mean_wgrad(const float* dy, const float* x, float* dw, int T, int B, long long inner,
+                                        int accumulate, void* stream) {
+    if (!dy || !x || !dw || T <= 0 || B <= 0 || inner <= 0) return VSPW_EINVAL;
+    hipLaunchKernelGGL(temporal_mean_wgrad_kernel, dim3(B * T), dim3(256), 0, vspw_stream(stream), dy, x, dw, T, B,
+                       inner, accumulate);
+    return vspw_launch_status();
+}
+
 extern "C" int vspw_temporal_mean_fwd(const float* x, const float* wts, float* y, int T, int B, long long inner,
                                       void* stream) {
     if (!x || !y || T <= 0 || B <= 0 || inner <= 0) return VSPW_EINVAL;

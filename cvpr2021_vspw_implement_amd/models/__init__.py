@@ -7,11 +7,10 @@ from .clip_ocr import ClipOCRNet  # noqa: F401
 from .ocrnet import SpatialOCRNet  # noqa: F401
 from .non_local import NLBlockND  # noqa: F401
 from .non_local_models import Non_local2d, Non_local3d  # noqa: F401
-from .netwarp import NetWarp, FlowCNN, flowwarp  # noqa: F401
+from .netwarp import NetWarp, NetWarp_ocr, FlowCNN, flowwarp  # noqa: F401
 
 ETC = _stub("ETC")
 ETC_ocr = _stub("ETC_ocr")
 PropNet = _stub("PropNet")
 OurWarpMerge = _stub("OurWarpMerge")
 WarpNet = _stub("WarpNet")
-NetWarp_ocr = _stub("NetWarp_ocr", "is a planned next row (SURVEY.md §8a a12); only NetWarp is built so far")

@@ -83,8 +83,6 @@ class Clip_PSP(LrGroupsMixin, nn.Module):
 
     def _temporal_weights(self, conv5, T):
         """softmax over the T frames of the pooled 1x1-conv score (clip_psp.py:147-152) -> [B, T]."""
-        if self.training:
-            raise NotImplementedError("psp_weight is implemented for inference only on the HIP path")
         score = self.pspweight_conv(conv5)  # [T*B,1,1,1]
         B = score.shape[0] // T
         return ops.row_softmax(score.reshape(T, B).t().contiguous(), 1.0).contiguous()

@@ -63,33 +63,34 @@ def _pad_to_8(x):
     return F.pad(x, pad, mode="replicate"), pad
 
 
-class NetWarp(LrGroupsMixin, nn.Module):
-    def __init__(self, net_enc, net_dec, crit, args, deep_sup_scale=None):
-        super().__init__()
+class _NetWarpBase(LrGroupsMixin, nn.Module):
+    """Shared flow / warp / blend plumbing of NetWarp (models/netwarp.py:66-239) and NetWarp_ocr
+    (models/netwarp_ocr.py:121-299)."""
+
+    def _init_common(self, net_enc, net_dec, crit, args, deep_sup_scale, blend2_channels, head=None):
+        # sub-module registration order = the reference's (it fixes the order of state_dict keys)
         self.raft = _load_flow_net(args)
         self.mean = torch.FloatTensor([0.485, 0.456, 0.406])
         self.std = torch.FloatTensor([0.229, 0.224, 0.225])
         self.encoder = net_enc
         self.decoder = net_dec
+        if head is not None:
+            self.head = head
         self.crit = crit
         self.deep_sup_scale = deep_sup_scale
         self.args = args
         assert self.args.clip_num == 2
         self.flowcnn = FlowCNN()
-        self.conv_last_ = vnn.FusedSequential(
-            vnn.Conv2d(2048 + 4 * 512, 512, kernel_size=3, padding=1, bias=False),
-            BatchNorm2d(512),
-            nn.ReLU(inplace=True),
-            nn.Dropout2d(0.1),
-            vnn.Conv2d(512, args.num_class, kernel_size=1),
-        )
         self.w0_0 = nn.Parameter(torch.ones(2048))
         self.w0_1 = nn.Parameter(torch.zeros(2048))
-        self.w1_0 = nn.Parameter(torch.ones(4096))
-        self.w1_1 = nn.Parameter(torch.zeros(4096))
+        self.w1_0 = nn.Parameter(torch.ones(blend2_channels))
+        self.w1_1 = nn.Parameter(torch.zeros(blend2_channels))
 
-    def _lr_10x_roots(self):
-        return [self.decoder, self.flowcnn, self.conv_last_]
+    def get_10x_lr_params(self):
+        for p in super().get_10x_lr_params():
+            yield p
+        for w in [self.w0_0, self.w1_0, self.w1_1, self.w0_1]:  # reference order
+            yield w
 
     def pixel_acc(self, pred, label):
         _, preds = torch.max(pred, dim=1)
@@ -107,12 +108,9 @@ class NetWarp(LrGroupsMixin, nn.Module):
             hh, ww = flow.shape[-2:]
             return flow[..., pad[2]:hh - pad[3], pad[0]:ww - pad[1]].contiguous()
 
-    def forward(self, feed_dict, *, segSize=None):
-        if feed_dict is None:
-            return torch.zeros((0, self.args.num_class, 480, 720)).cuda()
+    def _refined_flow(self, feed_dict):
         c_img = feed_dict["img_data"]
         clip_imgs = feed_dict["clipimgs_data"]
-        label = feed_dict["seg_label"]
         assert len(clip_imgs) == 1
         c_pre_img = clip_imgs[0]
         mean = self.mean.to(c_img.device).view(1, 3, 1, 1)
@@ -120,19 +118,42 @@ class NetWarp(LrGroupsMixin, nn.Module):
         c_img_f = (c_img * std + mean) * 255.0  # image un-normalisation: input plumbing for the flow net
         c_pre_img_f = (c_pre_img * std + mean) * 255.0
         flow = feed_dict["flow"] if "flow" in feed_dict else self._flow(c_img_f, c_pre_img_f)
-        flow = self.flowcnn(c_img_f, c_pre_img_f, flow)
+        return c_img, c_pre_img, self.flowcnn(c_img_f, c_pre_img_f, flow)
 
+    def _warp_blend(self, feats, flow, w_cur, w_warp):
+        """feats = [current; previous] stacked on the batch: blend the current half with the flow-warped previous."""
+        B = feats.shape[0] // 2
+        cur, prev = feats[:B], feats[B:]
+        flow_s = F.interpolate(flow, cur.shape[-2:], mode="nearest")  # nearest, magnitudes NOT rescaled (quirk)
+        return ops.chan_blend(cur, ops.flowwarp(prev, flow_s), w_cur, w_warp), prev
+
+
+class NetWarp(_NetWarpBase):
+    def __init__(self, net_enc, net_dec, crit, args, deep_sup_scale=None):
+        super().__init__()
+        self._init_common(net_enc, net_dec, crit, args, deep_sup_scale, 4096)
+        self.conv_last_ = vnn.FusedSequential(
+            vnn.Conv2d(2048 + 4 * 512, 512, kernel_size=3, padding=1, bias=False),
+            BatchNorm2d(512),
+            nn.ReLU(inplace=True),
+            nn.Dropout2d(0.1),
+            vnn.Conv2d(512, args.num_class, kernel_size=1),
+        )
+
+    def _lr_10x_roots(self):
+        return [self.decoder, self.flowcnn, self.conv_last_]
+
+    def forward(self, feed_dict, *, segSize=None):
+        if feed_dict is None:
+            return torch.zeros((0, self.args.num_class, 480, 720)).cuda()
+        label = feed_dict["seg_label"]
+        c_img, c_pre_img, flow = self._refined_flow(feed_dict)
         feats = self.encoder(torch.cat([c_img, c_pre_img], 0), return_feature_maps=True)
         B = c_img.shape[0]
-        conv5 = feats[-1]
-        cur1, prev1 = conv5[:B], conv5[B:]
-        flow_1 = F.interpolate(flow, cur1.shape[-2:], mode="nearest")  # nearest, magnitudes NOT rescaled (quirk)
-        new_cur1 = ops.chan_blend(cur1, ops.flowwarp(prev1, flow_1), self.w0_0, self.w0_1)
+        new_cur1, prev1 = self._warp_blend(feats[-1], flow, self.w0_0, self.w0_1)
         feats[-1] = torch.cat([new_cur1, prev1], 0)
         pred_deepsup_s, _, ppm_cat = self.decoder(feats)
-        cur2, prev2 = ppm_cat[:B], ppm_cat[B:]
-        flow_2 = F.interpolate(flow, cur2.shape[-2:], mode="nearest")
-        new_feat = ops.chan_blend(cur2, ops.flowwarp(prev2, flow_2), self.w1_0, self.w1_1)
+        new_feat, _ = self._warp_blend(ppm_cat, flow, self.w1_0, self.w1_1)
         pred_ = self.conv_last_(new_feat)
         if segSize is not None:
             return ops.upsample_softmax(pred_, segSize)
@@ -141,4 +162,58 @@ class NetWarp(LrGroupsMixin, nn.Module):
         if self.deep_sup_scale is not None:
             loss_deepsup, _ = ops.seg_nll(pred_deepsup_s[:B], label, ignore, want_acc=False, from_logits=False)
             loss = loss + loss_deepsup * self.deep_sup_scale
+        return loss, acc
+
+
+class SpatialOCRNetasDec(nn.Module):
+    """OCR decoder without the class head (models/netwarp_ocr.py:65-117): returns (512-ch OCR features, dsn logits)."""
+
+    def __init__(self, num_class):
+        self.inplanes = 128
+        super().__init__()
+        from .ocr_modules.spatial_ocr_block import SpatialGather_Module, SpatialOCR_Module
+        from .ocrnet import ocr_heads
+
+        self.num_classes = num_class
+        self.conv_3x3, _, dsn_head = ocr_heads(num_class)
+        self.spatial_context_head = SpatialGather_Module(self.num_classes)
+        self.spatial_ocr_head = SpatialOCR_Module(in_channels=512, key_channels=256, out_channels=512, scale=1,
+                                                  dropout=0.05)
+        self.dsn_head = dsn_head
+
+    def forward(self, x):
+        x_dsn = self.dsn_head(x[-2])
+        x = self.conv_3x3(x[-1])
+        context = self.spatial_context_head(x, x_dsn)
+        return self.spatial_ocr_head(x, context), x_dsn
+
+
+class NetWarp_ocr(_NetWarpBase):
+    def __init__(self, net_enc, crit, args, deep_sup_scale=None):
+        super().__init__()
+        self._init_common(net_enc, SpatialOCRNetasDec(args.num_class), crit, args, deep_sup_scale, 512,
+                          head=vnn.Conv2d(512, args.num_class, kernel_size=1, stride=1, padding=0, bias=True))
+
+    def _lr_10x_roots(self):
+        return [self.decoder, self.flowcnn, self.head]
+
+    def forward(self, feed_dict, *, segSize=None):
+        if feed_dict is None:
+            return torch.zeros((0, self.args.num_class, 480, 720)).cuda()
+        label = feed_dict["seg_label"]
+        c_img, c_pre_img, flow = self._refined_flow(feed_dict)
+        feats = self.encoder(torch.cat([c_img, c_pre_img], 0), return_feature_maps=True)
+        new_cur1, prev1 = self._warp_blend(feats[-1], flow, self.w0_0, self.w0_1)
+        feats[-1] = torch.cat([new_cur1, prev1], 0)
+        ocr_feats, x_dsn = self.decoder(feats)
+        new_feat, _ = self._warp_blend(ocr_feats, flow, self.w1_0, self.w1_1)
+        pred_ = self.head(new_feat)
+        if segSize is not None:
+            return ops.upsample_softmax(pred_, segSize)
+        ignore = nll_ignore_index(self.crit)
+        loss, acc = ops.seg_nll(pred_, label, ignore, want_acc=True, from_logits=True)
+        clip_label = feed_dict["cliplabels_data"]
+        clip_label.append(feed_dict["seg_label"])  # deepsup covers [previous..., current] = all 2B frames
+        loss_deepsup, _ = ops.seg_nll(x_dsn, torch.cat(clip_label, dim=0), ignore, want_acc=False, from_logits=True)
+        loss = loss + loss_deepsup * self.deep_sup_scale
         return loss, acc

@@ -456,6 +456,11 @@ class PyramidPoolFn(torch.autograd.Function):
         B = n // T
         st = _stream()
         outs = []
+        keep = []
+        if wts is not None:
+            wts = wts.contiguous()
+            if tuple(wts.shape) != (B, T):
+                raise RuntimeError("pyramid_pool: temporal weights must be [B, T] = [%d, %d]" % (B, T))
         for s in scales:
             pooled = empty_nhwc(n, c, s, s, x.device)
             _C.call("vspw_adaptive_avgpool_fwd", _p(x), _p(pooled), n, h, w, c, s, st)
@@ -463,15 +468,18 @@ class PyramidPoolFn(torch.autograd.Function):
                 blended = empty_nhwc(B, c, s, s, x.device)
                 _C.call("vspw_temporal_mean_fwd", _p(pooled), _p(wts), _p(blended), T, B, s * s * c, st)
                 outs.append(blended)
+                if wts is not None:
+                    keep.append(pooled)  # tiny ([n,c,s,s]); needed for the gradient of the temporal weights
             else:
                 outs.append(pooled)
         ctx.meta = (n, c, h, w, tuple(scales), T)
-        ctx.save_for_backward(wts)
+        ctx.save_for_backward(wts, *keep)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
-        (wts,) = ctx.saved_tensors
+        wts = ctx.saved_tensors[0]
+        pooled_all = ctx.saved_tensors[1:]
         n, c, h, w, scales, T = ctx.meta
         B = n // T
         st = _stream()
@@ -486,15 +494,22 @@ class PyramidPoolFn(torch.autograd.Function):
             _C.call("vspw_pyramid_pool_bwd", ptrs, svec, len(live), _p(dx), n, h, w, c, T, st)
             return dx, None, None, None
         first = True
+        dwts = None
+        if wts is not None and ctx.needs_input_grad[3]:
+            dwts = torch.empty_like(wts)
+        pooled_of = dict(zip(scales, pooled_all)) if pooled_all else {}
         for s, g in live:
             if T > 1:
                 gp = empty_nhwc(n, c, s, s, dev)
                 _C.call("vspw_temporal_mean_bwd", _p(g), _p(wts), _p(gp), T, B, s * s * c, st)
+                if dwts is not None:
+                    _C.call("vspw_temporal_mean_wgrad", _p(g), _p(pooled_of[s]), _p(dwts), T, B, s * s * c,
+                            0 if first else 1, st)
             else:
                 gp = g
             _C.call("vspw_adaptive_avgpool_bwd", _p(gp), _p(dx), n, h, w, c, s, 0 if first else 1, st)
             first = False
-        return dx, None, None, None
+        return dx, None, None, dwts
 
 
 def pyramid_pool(x, scales, T=1, wts=None):

@@ -116,6 +116,11 @@ int vspw_temporal_mean_fwd(const float* x, const float* wts, float* y, int T, in
 int vspw_temporal_mean_bwd(const float* dy, const float* wts, float* dx, int T, int B, long long inner,
                            void* stream);
 
+/* dwts[b*T + j] (+)= (1/T) * <dy[b], x[frame j of clip b]>: gradient of the psp_weight temporal weights
+ * (models/clip_psp.py:147-152,184-186). */
+int vspw_temporal_mean_wgrad(const float* dy, const float* x, float* dw, int T, int B, long long inner,
+                             int accumulate, void* stream);
+
 /* ---------------------------------------------------------------- bilinear (interp.hip) ----------- */
 /* F.interpolate(mode='bilinear', align_corners=False) (models/clip_psp.py:49-52, models/models.py:96,102).
  * Output rows have ldo channels and the result lands at channel offset co (writes straight into the PPM concat).

@@ -39,6 +39,8 @@ def build(kind, arch, decoder=None, fc_dim=2048, **kw):
     if kind == "netwarp":
         dec = M.ModelBuilder.build_decoder(arch="ppm_deepsup_clip", fc_dim=fc_dim, num_class=K)
         return M.NetWarp(enc, dec, crit, args_ns(clip_num=2, flow_net=kw["flow_net"]), deep_sup_scale=0.4)
+    if kind == "netwarp_ocr":
+        return M.NetWarp_ocr(enc, crit, args_ns(clip_num=2, flow_net=kw["flow_net"]), deep_sup_scale=0.4)
     raise ValueError(kind)
 
 

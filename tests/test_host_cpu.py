@@ -56,12 +56,17 @@ def test_r101_keycounts_match_survey():
     assert len(build("clip_ocr", "resnet101dilated").state_dict()) == 703
 
 
-def test_netwarp_state_dict():
+@pytest.mark.parametrize("kind", ["netwarp", "netwarp_ocr"])
+def test_netwarp_state_dict_and_param_groups(kind):
     fx = golden("state_keys")
-    mod = build("netwarp", "resnet50dilated", flow_net=torch.nn.Identity())
+    mod = build(kind, "resnet50dilated", flow_net=torch.nn.Identity())
     ks, shapes = _keys(mod, skip=("raft.",))
-    assert ks == [str(k) for k in fx["netwarp:resnet50dilated:keys"]]
-    assert shapes == [str(s) for s in fx["netwarp:resnet50dilated:shapes"]]
+    name = kind + ":resnet50dilated"
+    assert ks == [str(k) for k in fx[name + ":keys"]]
+    assert shapes == [str(s) for s in fx[name + ":shapes"]]
+    ids = {id(p): k for k, p in mod.named_parameters()}
+    for g in ("get_1x_lr_params", "get_10x_lr_params", "get_1x_lr_params_bias", "get_10x_lr_params_bias"):
+        assert [ids[id(p)] for p in getattr(mod, g)()] == [str(k) for k in fx["%s:%s" % (name, g)]], g
 
 
 @pytest.mark.parametrize("arch", ["resnet18dilated", "resnet101dilated"])
@@ -84,7 +89,7 @@ def test_builder_errors_and_stubs():
         M.ModelBuilder.build_decoder(arch="fcn")
     with pytest.raises(NotImplementedError):
         M.ModelBuilder.build_encoder(arch="resnet34")
-    for name in ("ClipWarpNet", "ETC", "PropNet", "OurWarpMerge", "NetWarp_ocr", "ETC_ocr"):
+    for name in ("ClipWarpNet", "ETC", "PropNet", "OurWarpMerge", "ETC_ocr"):
         with pytest.raises(NotImplementedError):
             getattr(M, name)()
     from cvpr2021_vspw_implement_amd.models.sync_batchnorm.replicate import patch_replication_callback

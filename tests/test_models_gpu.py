@@ -193,6 +193,78 @@ def test_netwarp(dev):
     _check_train(fx, mod, loss, acc, tag)
 
 
+def test_netwarp_ocr(dev):
+    tag = "r50_netwarp_ocr"
+    fx = golden(tag)
+    shape = (2, 3, 65, 65)
+
+    class FakeRaft(torch.nn.Module):
+        def forward(self, a, b, iters=20, test_mode=True):
+            n, _, h, w = a.shape
+            f = torch.from_numpy(det_input(tag + ":flow", (n, 2, h, w), scale=1.9)) - 0.7
+            return None, f.clamp(-10, 10).to(a.device)
+
+    mod = build("netwarp_ocr", "resnet50dilated", flow_net=FakeRaft())
+    load_det(mod, skip_prefix=("raft.",))
+    zero_dropout(mod)
+    mod.to(dev)
+    mod.train()
+    cur = _t(det_input(tag + ":cur", shape), dev)
+    prev = _t(det_input(tag + ":prev", shape), dev)
+    lab = _t(det_labels(tag + ":lab", (2, 1, 65, 65), K), dev)
+    plab = _t(det_labels(tag + ":plab", (2, 1, 65, 65), K), dev)
+    loss, acc = mod({"img_data": cur, "seg_label": lab, "clipimgs_data": [prev], "cliplabels_data": [plab]})
+    loss.backward()
+    _check_train(fx, mod, loss, acc, tag)
+
+
+def test_clip_psp_temporal_weights(dev):
+    """args.psp_weight: softmax-over-T weighting of the pooled features (clip_psp.py:147-152,184-186), forward and
+    the gradient of pspweight_conv."""
+    tag = "r50_clip_psp_pspw"
+    fx = golden(tag)
+    mod = build("clip_psp", "resnet50dilated", args={"psp_weight": True})
+    load_det(mod, fx=fx)
+    zero_dropout(mod)
+    mod.to(dev)
+    inp = clip_inputs(tag)
+    mod.eval()
+    store = {}
+    h = _hook(mod.ppm_conv.conv_last_, store)
+    ev = [_t(a, dev) for a in inp["eval_imgs"]]
+    with torch.no_grad():
+        probs = mod({"img_data": ev[-1], "clipimgs_data": ev[:-1], "seg_label": torch.zeros(1, 1, 64, 96, device=dev)},
+                    segSize=(64, 96))
+    h.remove()
+    _check_eval(fx, probs, store)
+    mod.train()
+    imgs = [_t(a, dev) for a in inp["train_imgs"]]
+    labs = [_t(a, dev) for a in inp["train_labs"]]
+    loss, acc = mod({"img_data": imgs[-1], "seg_label": labs[-1], "clipimgs_data": imgs[:-1],
+                     "cliplabels_data": labs[:-1]})
+    loss.backward()
+    _check_train(fx, mod, loss, acc, tag)
+    assert mod.pspweight_conv[0].weight.grad is not None
+
+
+def test_clip_ocr_memory_bank(dev):
+    """use_memory inference over three consecutive frames (is_clean_memory on the first)."""
+    tag = "r50_clip_ocr_memory"
+    fx = golden(tag)
+    mod = build("clip_ocr", "resnet50dilated", args={"use_memory": True, "memory_num": 4})
+    load_det(mod, fx=fx)
+    mod.to(dev).eval()
+    shape = (1, 3, 64, 96)
+    for c in range(3):
+        imgs = [_t(det_input("%s:call%d:%d" % (tag, c, t), shape), dev) for t in range(3)]
+        with torch.no_grad():
+            probs = mod({"img_data": imgs[-1], "clipimgs_data": imgs[:-1], "is_clean_memory": c == 0,
+                         "seg_label": torch.zeros(1, 1, 64, 96, device=dev)}, segSize=(64, 96))
+        assert len(mod.memory) == int(fx["call%d_memlen" % c])
+        err = np.abs(probs.float().cpu().numpy()[:, :, ::4, ::4] - fx["call%d_probs_sub" % c]).max()
+        assert err < 2e-3, (c, err)
+
+
 def test_bench_shape_properties(dev):
     """BASELINE-size (T=5, B=2, 479x479, R101 TCB-PSP) size-independent properties: the step runs, loss is finite and
     ~log(K) at init, every parameter receives a finite gradient, and the loss is linear in the incoming gradient

@@ -184,12 +184,12 @@ def case_segmodule(M, arch, decoder, tag, train_shape=(2, 3, 65, 65), eval_shape
     print(tag, "loss %.6f acc %.4f" % (loss.item(), acc.item()))
 
 
-def case_clip(M, method, arch, tag, T=3, train_shape=(2, 3, 65, 65), eval_shape=(1, 3, 64, 96)):
+def case_clip(M, method, arch, tag, T=3, train_shape=(2, 3, 65, 65), eval_shape=(1, 3, 64, 96), **argkw):
     torch.manual_seed(0)
     enc = M.ModelBuilder.build_encoder(arch=arch, fc_dim=2048)
     crit = torch.nn.NLLLoss(ignore_index=255)
     cls = {"clip_psp": M.Clip_PSP, "clip_ocr": M.ClipOCRNet}[method]
-    mod = cls(enc, crit, args_ns(), deep_sup_scale=0.4)
+    mod = cls(enc, crit, args_ns(**argkw), deep_sup_scale=0.4)
     load_det(mod)
     zero_dropout(mod)
     res = {}
@@ -232,6 +232,67 @@ def case_clip(M, method, arch, tag, T=3, train_shape=(2, 3, 65, 65), eval_shape=
         lambda: mod({"img_data": eimgs[-1], "clipimgs_data": list(eimgs[:-1]),
                      "seg_label": torch.zeros(eval_shape[0], 1, *eval_shape[2:])}, segSize=eval_shape[2:])))
     res["meta"] = np.array([arch, method, str(T), str(train_shape), str(eval_shape)])
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, "loss %.6f acc %.4f" % (loss.item(), acc.item()))
+
+
+def case_ocr_memory(M, arch, tag, T=3, shape=(1, 3, 64, 96), calls=3, memory_num=4):
+    """ClipOCRNet inference with the context memory bank (use_memory): three consecutive frames of one video; pins
+    the bank's (quirky) persistence rule of spatial_ocr_block.py:110-125."""
+    torch.manual_seed(0)
+    enc = M.ModelBuilder.build_encoder(arch=arch, fc_dim=2048)
+    mod = M.ClipOCRNet(enc, torch.nn.NLLLoss(ignore_index=255), args_ns(use_memory=True, memory_num=memory_num),
+                       deep_sup_scale=0.4)
+    load_det(mod)
+    cimgs = [torch.from_numpy(det_input("%s:cal:%d" % (tag, t), (2, 3, 65, 65))) for t in range(T)]
+    clabs = [torch.from_numpy(det_labels("%s:cal:%d" % (tag, t), (2, 1, 65, 65), K)) for t in range(T)]
+    res = calibrate_bn(mod, lambda: mod({"img_data": cimgs[-1], "seg_label": clabs[-1],
+                                         "clipimgs_data": list(cimgs[:-1]), "cliplabels_data": list(clabs[:-1])}))
+    mod.eval()
+    for c in range(calls):
+        imgs = [torch.from_numpy(det_input("%s:call%d:%d" % (tag, c, t), shape)) for t in range(T)]
+        with torch.no_grad():
+            probs = mod({"img_data": imgs[-1], "clipimgs_data": imgs[:-1], "is_clean_memory": c == 0,
+                         "seg_label": torch.zeros(shape[0], 1, *shape[2:])}, segSize=shape[2:])
+        res["call%d_probs_sub" % c] = probs.numpy()[:, :, ::4, ::4].copy()
+        res["call%d_memlen" % c] = np.int64(len(mod.memory))
+    res["meta"] = np.array([arch, "clip_ocr_memory", str(T), str(shape), str(calls), str(memory_num)])
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, "memory lens", [int(res["call%d_memlen" % c]) for c in range(calls)])
+
+
+def case_netwarp_ocr(M, arch, tag, shape=(2, 3, 65, 65)):
+    import models.netwarp_ocr as ref_nw
+
+    class FakeRaft(torch.nn.Module):
+        def forward(self, a, b, iters=20, test_mode=True):
+            n, _, h, w = a.shape
+            f = torch.from_numpy(det_input(tag + ":flow", (n, 2, h, w), scale=1.9)) - 0.7
+            return None, f.clamp(-10, 10)
+
+    orig_raft, orig_load = ref_nw.RAFT, torch.load
+    ref_nw.RAFT = lambda: torch.nn.Identity()
+    torch.load = lambda *a, **k: {}
+    torch.manual_seed(0)
+    try:
+        enc = M.ModelBuilder.build_encoder(arch=arch, fc_dim=2048)
+        mod = M.NetWarp_ocr(enc, torch.nn.NLLLoss(ignore_index=255), args_ns(clip_num=2), deep_sup_scale=0.4)
+    finally:
+        ref_nw.RAFT, torch.load = orig_raft, orig_load
+    mod.raft = FakeRaft()
+    sd = {k: v for k, v in mod.state_dict().items() if not k.startswith("raft.")}
+    mod.load_state_dict({k: torch.from_numpy(det_tensor(k, v.shape)).to(v.dtype) for k, v in sd.items()}, strict=False)
+    zero_dropout(mod)
+    mod.train()
+    cur = torch.from_numpy(det_input(tag + ":cur", shape))
+    prev = torch.from_numpy(det_input(tag + ":prev", shape))
+    lab = torch.from_numpy(det_labels(tag + ":lab", (shape[0], 1) + shape[2:], K))
+    plab = torch.from_numpy(det_labels(tag + ":plab", (shape[0], 1) + shape[2:], K))
+    loss, acc = mod({"img_data": cur, "seg_label": lab, "clipimgs_data": [prev], "cliplabels_data": [plab]})
+    loss.backward()
+    res = {"train_loss": np.float64(loss.item()), "train_acc": np.float64(acc.item())}
+    res.update(grads_summary(mod, full=("w0_1", "w1_0", "flowcnn.conv4.0.weight")))
+    res["meta"] = np.array([arch, "netwarp_ocr", str(shape)])
     np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
     print(tag, "loss %.6f acc %.4f" % (loss.item(), acc.item()))
 
@@ -363,10 +424,23 @@ def case_keys(M, tag="state_keys"):
         nw = M.NetWarp(enc, d, crit, args_ns(clip_num=2), deep_sup_scale=0.4)
     finally:
         ref_nw.RAFT, torch.load = orig_raft, orig_load
-    sd = nw.state_dict()
-    res["netwarp:resnet50dilated:keys"] = np.array([k for k in sd if not k.startswith("raft.")])
-    res["netwarp:resnet50dilated:shapes"] = np.array([str(tuple(v.shape)) for k, v in sd.items()
-                                                      if not k.startswith("raft.")])
+    import models.netwarp_ocr as ref_nwo
+
+    orig_raft2 = ref_nwo.RAFT
+    ref_nwo.RAFT = lambda: torch.nn.Identity()
+    torch.load = lambda *a, **k: {}
+    try:
+        enc = M.ModelBuilder.build_encoder(arch="resnet50dilated", fc_dim=2048)
+        nwo = M.NetWarp_ocr(enc, crit, args_ns(clip_num=2), deep_sup_scale=0.4)
+    finally:
+        ref_nwo.RAFT, torch.load = orig_raft2, orig_load
+    for name, m_ in (("netwarp:resnet50dilated", nw), ("netwarp_ocr:resnet50dilated", nwo)):
+        sd = m_.state_dict()
+        res[name + ":keys"] = np.array([k for k in sd if not k.startswith("raft.")])
+        res[name + ":shapes"] = np.array([str(tuple(v.shape)) for k, v in sd.items() if not k.startswith("raft.")])
+        ids = {id(p): k for k, p in m_.named_parameters()}
+        for g in ("get_1x_lr_params", "get_10x_lr_params", "get_1x_lr_params_bias", "get_10x_lr_params_bias"):
+            res["%s:%s" % (name, g)] = np.array([ids[id(p)] for p in getattr(m_, g)()])
     # BN init of build_decoder(weights_init) and default conv geometry after _nostride_dilate
     enc = M.ModelBuilder.build_encoder(arch="resnet101dilated", fc_dim=2048)
     geo = []
@@ -411,6 +485,12 @@ def main():
         case_nonlocal3d(M, "resnet50dilated", "r50_nonlocal3d")
     if want("r50_netwarp"):
         case_netwarp(M, "resnet50dilated", "r50_netwarp")
+    if want("r50_netwarp_ocr"):
+        case_netwarp_ocr(M, "resnet50dilated", "r50_netwarp_ocr")
+    if want("r50_clip_psp_pspw"):
+        case_clip(M, "clip_psp", "resnet50dilated", "r50_clip_psp_pspw", psp_weight=True)
+    if want("r50_clip_ocr_memory"):
+        case_ocr_memory(M, "resnet50dilated", "r50_clip_ocr_memory")
 
 
 if __name__ == "__main__":

@@ -281,12 +281,14 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
 //     ds_writes and ds_reads issue in the shadow of the 64-cycle fp32 MFMAs instead of in front of them;
 //   * (tap, channel) of a thread's k-column advance incrementally: no integer division in the loop.
 // MODE 0: forward gather (any stride);  MODE 1: data-gradient gather, stride 1.
-template <int WM, int WN, int MODE>
+// NBUF 2: as described.  NBUF 1: one LDS buffer and two barriers per K-tile (half the LDS, so the 64-row tiles keep
+// 4 workgroups per CU resident) but the same straight-line, MFMA-shadowed load path.
+template <int WM, int WN, int MODE, int NBUF>
 __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
     constexpr int TM = 64 * WM, TN = 64 * WN;
     constexpr int RA = TM / 32, RB = TN / 32;
-    __shared__ __attribute__((aligned(16))) float As[2][TM * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][TN * LDA];
+    __shared__ __attribute__((aligned(16))) float As[NBUF][TM * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[NBUF][TN * LDA];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -398,13 +400,20 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
     const int nk = (p.kdim + BK - 1) / BK;
     // prologue: tile 0 -> LDS[0]; tile 1 -> registers
     load_tile();
-    store_tile(As[0], Bs[0]);
-    advance();  // state now describes tile 1 (loads past kdim are zeroed at store time)
-    load_tile();
-    __syncthreads();
+    if (NBUF == 2) {
+        store_tile(As[0], Bs[0]);
+        advance();  // state now describes tile 1 (loads past kdim are zeroed at store time)
+        load_tile();
+        __syncthreads();
+    }
 
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+        const int cur = (NBUF == 2) ? (kt & 1) : 0;
+        if (NBUF == 1) {
+            store_tile(As[0], Bs[0]);  // tile kt (loaded during iteration kt-1)
+            __syncthreads();
+            advance();
+        }
         const float* Ac = As[cur];
         const float* Bc = Bs[cur];
 #pragma unroll
@@ -424,12 +433,14 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
                     for (int j = 0; j < WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
             if (kc == 0) {
-                // tile kt+1 has been in flight since the middle of the previous iteration: registers -> the other
-                // LDS buffer (its last readers passed the barrier that ended iteration kt-1), then reuse the
-                // registers for tile kt+2, which gets a whole iteration to land.
-                store_tile(As[cur ^ 1], Bs[cur ^ 1]);
-                advance();
-                load_tile();
+                if (NBUF == 2) {
+                    // tile kt+1 has been in flight since the middle of the previous iteration: registers -> the
+                    // other LDS buffer (its last readers passed the barrier that ended iteration kt-1), then reuse
+                    // the registers for tile kt+2, which gets a whole iteration to land.
+                    store_tile(As[(NBUF - 1) & (cur ^ 1)], Bs[(NBUF - 1) & (cur ^ 1)]);
+                    advance();
+                }
+                load_tile();  // NBUF 1: tile kt+1, consumed at the top of the next iteration
             }
         }
         __syncthreads();
@@ -497,22 +508,22 @@ template <int MODE>
 static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
     if (cfg == 22) {
         int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, MODE>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, MODE, 2>), dim3(tiles), dim3(256), 0, st, p);
     } else if (cfg == 12) {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 2, MODE>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 2, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
     } else {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 1, MODE>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 1, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
     }
 }
 
 static int launch_igemm_nt(const IgemmNT& p, int cfg, hipStream_t st) {
     const long long src_elems = (long long)p.nb * p.h * p.w * p.c;
     const long long wt_elems = (long long)p.nout * p.kdim;
-    // measured (profiles/r01_c_kernel_report.csv): v2 wins 5-12 % on the 128x128 tile; on the 64-row tiles its two LDS
-    // buffers cap residency at 2 workgroups/CU and the single-buffer kernel (4/CU) is faster
-    const bool v2 = cfg == 22 && p.vec && p.c >= BK && src_elems < 0x7fffffffLL && wt_elems < 0x7fffffffLL &&
+    // measured (profiles/r01_*_kernel_report*.csv): the straight-line v2 pipeline wins 5-12 % everywhere; the 128x128
+    // tile uses two LDS buffers, the 64-row tiles one (two would cap residency at 2 workgroups/CU and lose)
+    const bool v2 = cfg != 21 && p.vec && p.c >= BK && src_elems < 0x7fffffffLL && wt_elems < 0x7fffffffLL &&
                     (p.mode == 0 || p.stride == 1);
     if (v2) {
         if (p.mode == 0)

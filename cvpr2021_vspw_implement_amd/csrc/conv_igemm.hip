@@ -701,6 +701,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(IgemmTN p) {
 // igemm_nt_v2_kernel — two LDS buffers, one barrier per 32-pixel K-tile, straight-line loop body with clamped
 // always-valid addresses (zeroing applied when the registers are written to LDS), next-next tile's global loads issued
 // in the shadow of the MFMAs.
+template <bool WIDE>
 __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
@@ -739,24 +740,48 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     }
     const int ohw = p.oh * p.ow;
 
-    f32x4 ra[4], rb[4];
-    bool oka[4], okb[4];
-    auto load_tile = [&](int pk0) {
+    // pixel state of the 4 rows this thread stages: (image, oy, ox) advance by BK pixels per K-tile.  When the row
+    // is at least BK wide the update is a compare/select chain; otherwise fall back to two integer divisions.
+    int r_pp[4], r_n[4], r_oy[4], r_ox[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r_pp[i] = p_begin + krow + 8 * i;
+        r_n[i] = r_pp[i] / ohw;
+        const int r = r_pp[i] - r_n[i] * ohw;
+        r_oy[i] = r / p.ow;
+        r_ox[i] = r - r_oy[i] * p.ow;
+    }
+    auto advance = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int pp = pk0 + krow + 8 * i;
-            const bool pin = pp < p_end;
-            const int pc = pin ? pp : p_begin;
+            r_pp[i] += BK;
+            if (WIDE) {  // ow >= BK: at most one row wrap per step
+                r_ox[i] += BK;
+                const bool wx = r_ox[i] >= p.ow;
+                r_ox[i] = wx ? r_ox[i] - p.ow : r_ox[i];
+                r_oy[i] = wx ? r_oy[i] + 1 : r_oy[i];
+                const bool wy = r_oy[i] >= p.oh;
+                r_oy[i] = wy ? 0 : r_oy[i];
+                r_n[i] = wy ? r_n[i] + 1 : r_n[i];
+            } else {
+                r_n[i] = r_pp[i] / ohw;
+                const int r = r_pp[i] - r_n[i] * ohw;
+                r_oy[i] = r / p.ow;
+                r_ox[i] = r - r_oy[i] * p.ow;
+            }
+        }
+    };
+    f32x4 ra[4], rb[4];
+    bool oka[4], okb[4];
+    auto load_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool pin = r_pp[i] < p_end;
             oka[i] = pin & a_colok;
-            ra[i] = *reinterpret_cast<const f32x4*>(p.dy + (pc * p.k + (a_colok ? co : 0)));
-            const int n = pc / ohw;
-            const int r = pc - n * ohw;
-            const int oy = r / p.ow;
-            const int ox = r - oy * p.ow;
-            const int sy = oy * p.stride + b_dy, sx = ox * p.stride + b_dx;
+            ra[i] = *reinterpret_cast<const f32x4*>(p.dy + (oka[i] ? r_pp[i] * p.k + co : 0));
+            const int sy = r_oy[i] * p.stride + b_dy, sx = r_ox[i] * p.stride + b_dx;
             okb[i] = pin & b_colok & ((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w);
-            const int syc = min(max(sy, 0), p.h - 1), sxc = min(max(sx, 0), p.w - 1);
-            rb[i] = *reinterpret_cast<const f32x4*>(p.x + (((n * p.h + syc) * p.w + sxc) * p.c + b_ci));
+            rb[i] = *reinterpret_cast<const f32x4*>(p.x + (okb[i] ? ((r_n[i] * p.h + sy) * p.w + sx) * p.c + b_ci : 0));
         }
     };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -778,9 +803,10 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
 
     const int nk = (p_end - p_begin + BK - 1) / BK;
     if (nk > 0) {
-        load_tile(p_begin);
+        load_tile();
         store_tile(As[0], Bs[0]);
-        load_tile(p_begin + BK);  // rows past p_end are zeroed at store time
+        advance();
+        load_tile();  // rows past p_end are zeroed at store time
         __syncthreads();
     }
     for (int kt = 0; kt < nk; ++kt) {
@@ -801,8 +827,9 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             if (s == 3) {
-                store_tile(As[cur ^ 1], Bs[cur ^ 1]);        // tile kt+1 (in flight since the previous iteration)
-                load_tile(p_begin + (kt + 2) * BK);          // tile kt+2 gets a whole iteration to land
+                store_tile(As[cur ^ 1], Bs[cur ^ 1]);  // tile kt+1 (in flight since the previous iteration)
+                advance();
+                load_tile();                           // tile kt+2 gets a whole iteration to land
             }
         }
         __syncthreads();
@@ -963,8 +990,10 @@ extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, 
     int tiles = vspw_cdiv(p.k, BM) * vspw_cdiv(p.ncols, BN);
     const bool v2 = p.vec_a && p.vec_b && (long long)p.P * p.k < 0x7fffffffLL &&
                     (long long)d->n * d->h * d->w * d->c < 0x7fffffffLL;
-    if (v2)
-        hipLaunchKernelGGL(igemm_tn_v2_kernel, dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
+    if (v2 && p.ow >= BK)
+        hipLaunchKernelGGL(igemm_tn_v2_kernel<true>, dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
+    else if (v2)
+        hipLaunchKernelGGL(igemm_tn_v2_kernel<false>, dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
     else
         hipLaunchKernelGGL(igemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
     int st = vspw_launch_status();

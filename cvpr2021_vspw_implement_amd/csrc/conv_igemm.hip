@@ -283,9 +283,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
 // MODE 0: forward gather (any stride);  MODE 1: data-gradient gather, stride 1.
 // NBUF 2: as described.  NBUF 1: one LDS buffer and two barriers per K-tile (half the LDS, so the 64-row tiles keep
 // 4 workgroups per CU resident) but the same straight-line, MFMA-shadowed load path.
-template <int WM, int WN, int MODE, int NBUF>
+// WGM = waves along M (2: 2x2 waves, 1: 1x4 waves); workgroup tile = (32*WM*WGM) x (32*WN*(4/WGM)).
+template <int WGM, int WM, int WN, int MODE, int NBUF>
 __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
-    constexpr int TM = 64 * WM, TN = 64 * WN;
+    constexpr int WGN = 4 / WGM;
+    constexpr int TM = 32 * WM * WGM, TN = 32 * WN * WGN;
     constexpr int RA = TM / 32, RB = TN / 32;
     __shared__ __attribute__((aligned(16))) float As[NBUF][TM * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[NBUF][TN * LDA];
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = (WGM == 2) ? (wave >> 1) : 0, wn = (WGM == 2) ? (wave & 1) : wave;
     const int l31 = lane & 31, lh = lane >> 5;
 
     const int tiles_n = (p.nout + TN - 1) / TN;
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
         }
     }
     if (p.stat_part != nullptr) {
-        float* red = As[0];
+        float* red = As[0];  // [2 stats][WGM][TN]  (TM*LDA >= 2*WGM*TN for every instantiated tile)
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
@@ -477,8 +479,8 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
             float q = csq[j] + __shfl_xor(csq[j], 32, 64);
             if (lh == 0) {
                 int c = wn * 32 * WN + j * 32 + l31;
-                red[(0 * 2 + wm) * TN + c] = s;
-                red[(1 * 2 + wm) * TN + c] = q;
+                red[(0 * WGM + wm) * TN + c] = s;
+                red[(1 * WGM + wm) * TN + c] = q;
             }
         }
         __syncthreads();
@@ -486,45 +488,78 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
             int col = n0 + tid;
             if (col < p.nout) {
                 float* out = p.stat_part + (size_t)tile_m * 2 * p.nout;
-                out[col] = red[0 * TN + tid] + red[1 * TN + tid];
-                out[p.nout + col] = red[2 * TN + tid] + red[3 * TN + tid];
+                float s = red[tid], q = red[WGM * TN + tid];
+                if (WGM == 2) {
+                    s += red[TN + tid];
+                    q += red[3 * TN + tid];
+                }
+                out[col] = s;
+                out[p.nout + col] = q;
             }
         }
     }
 }
 
-// Tile choice: fp32 MFMA work is uniform per tile, so the only scheduling loss is the tail; prefer the big tile
-// (fewest LDS/global bytes per FLOP) when it still yields >= 4 workgroups per CU, otherwise halve the tile.
+// Tile choice.  fp32 MFMA work is uniform per output element, so apart from a small per-tile efficiency difference
+// (bigger tiles amortise barriers and fragment loads better) the scheduling loss is the tail: with workgroups handed
+// out greedily, the busiest of the 256 CUs processes ceil(workgroups / 256) tiles.  Pick the tile height that
+// minimises  ceil(wg/256) * rows / efficiency  among 128 (2x2 waves of 2x2 MFMA tiles), 96 (1x4 waves of 3x1) and
+// 64 (2x2 waves of 1x2).  Codes: 22 / 31 / 12; narrow outputs (Cout <= 64, the stem) use 128x64 (21) or 64x64 (11).
 static int nt_pick_tile(long long m, int nout) {
-    if (nout <= 64) return (((m + 127) / 128) >= 1024) ? 21 : 11;  // narrow outputs (stem): 128x64 tile when M is large
-    const long long b22 = ((m + 127) / 128) * ((nout + 127) / 128);
-    if (b22 >= 1024) return 22;
-    return 12;
+    if (nout <= 64) return (((m + 127) / 128) >= 1024) ? 21 : 11;
+    const long long tn = (nout + 127) / 128;
+    const int rows[3] = {128, 96, 64};
+    const int code[3] = {22, 31, 12};
+    const double eff[3] = {1.0, 0.97, 0.92};
+    int best = 0;
+    double best_cost = 1e300;
+    for (int i = 0; i < 3; ++i) {
+        const long long wg = ((m + rows[i] - 1) / rows[i]) * tn;
+        const double cost = (double)((wg + 255) / 256) * rows[i] / eff[i];
+        if (cost < best_cost * 0.999) {
+            best_cost = cost;
+            best = i;
+        }
+    }
+    return code[best];
 }
 
-static int nt_tile_rows(int cfg) { return (cfg == 22 || cfg == 21) ? 128 : 64; }
+static int nt_tile_rows(int cfg) { return (cfg == 22 || cfg == 21) ? 128 : (cfg == 31 ? 96 : 64); }
 
 template <int MODE>
 static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
     if (cfg == 22) {
         int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, MODE, 2>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 2>), dim3(tiles), dim3(256), 0, st, p);
+    } else if (cfg == 31) {
+        int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
     } else if (cfg == 12) {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 2, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
     } else {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 1, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
     }
 }
 
-static int launch_igemm_nt(const IgemmNT& p, int cfg, hipStream_t st) {
+// Final (tile code, use-v2) decision for a launch; shared by the launcher and vspw_conv2d_stats_partials so that the
+// number of per-tile BN partial rows the caller allocates always matches the kernel that runs.
+// measured (profiles/r01_*): the straight-line v2 pipeline wins 5-12 % everywhere; the 128x128 tile uses two LDS
+// buffers, the smaller tiles one (two would cap residency at 2 workgroups/CU and lose)
+static int nt_decide(const IgemmNT& p, bool& v2) {
+    int cfg = nt_pick_tile(p.m, p.nout);
     const long long src_elems = (long long)p.nb * p.h * p.w * p.c;
     const long long wt_elems = (long long)p.nout * p.kdim;
-    // measured (profiles/r01_*_kernel_report*.csv): the straight-line v2 pipeline wins 5-12 % everywhere; the 128x128
-    // tile uses two LDS buffers, the 64-row tiles one (two would cap residency at 2 workgroups/CU and lose)
-    const bool v2 = cfg != 21 && p.vec && p.c >= BK && src_elems < 0x7fffffffLL && wt_elems < 0x7fffffffLL &&
-                    (p.mode == 0 || p.stride == 1);
+    v2 = cfg != 21 && p.vec && p.c >= BK && src_elems < 0x7fffffffLL && wt_elems < 0x7fffffffLL &&
+         (p.mode == 0 || p.stride == 1);
+    if (!v2 && cfg == 31) cfg = 12;  // the generic kernel has no 96-row instantiation
+    return cfg;
+}
+
+static int launch_igemm_nt(const IgemmNT& p, hipStream_t st) {
+    bool v2;
+    const int cfg = nt_decide(p, v2);
     if (v2) {
         if (p.mode == 0)
             launch_nt_v2<0>(p, cfg, st);
@@ -900,29 +935,37 @@ static int conv_geometry_ok(const vspw_conv_desc* d) {
     return oh == d->oh && ow == d->ow && oh > 0 && ow > 0;
 }
 
-extern "C" size_t vspw_conv2d_stats_partials(const vspw_conv_desc* d) {
-    if (!d) return 0;
-    long long m = (long long)d->n * d->oh * d->ow;
-    const int rows = nt_tile_rows(nt_pick_tile(m, d->k));
-    return (size_t)((m + rows - 1) / rows);
-}
-
-extern "C" int vspw_conv2d_fwd(const vspw_conv_desc* d, const float* x, const float* w, const float* bias,
-                               float* y, float* stat_part, void* stream) {
-    if (!conv_geometry_ok(d) || !x || !w || !y) return VSPW_EINVAL;
-    IgemmNT p;
-    p.src = x; p.wt = w; p.bias = bias; p.dst = y; p.stat_part = stat_part;
+static bool fill_fwd_params(const vspw_conv_desc* d, IgemmNT& p) {
+    p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr;
     p.nb = d->n; p.h = d->h; p.w = d->w; p.c = d->c;
     p.oh = d->oh; p.ow = d->ow;
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.mode = 0;
     p.nout = d->k; p.ldd = d->k;
     long long m = (long long)d->n * d->oh * d->ow;
-    if (m > 0x7fffffffLL) return VSPW_EINVAL;
+    if (m > 0x7fffffffLL) return false;
     p.m = (int)m;
     p.kdim = d->kh * d->kw * d->c;
     p.vec = (d->c % 4 == 0) ? 1 : 0;
-    return launch_igemm_nt(p, nt_pick_tile(p.m, p.nout), vspw_stream(stream));
+    return true;
+}
+
+extern "C" size_t vspw_conv2d_stats_partials(const vspw_conv_desc* d) {
+    if (!conv_geometry_ok(d)) return 0;
+    IgemmNT p;
+    if (!fill_fwd_params(d, p)) return 0;
+    bool v2;
+    const int rows = nt_tile_rows(nt_decide(p, v2));
+    return (size_t)((p.m + rows - 1) / rows);
+}
+
+extern "C" int vspw_conv2d_fwd(const vspw_conv_desc* d, const float* x, const float* w, const float* bias,
+                               float* y, float* stat_part, void* stream) {
+    if (!conv_geometry_ok(d) || !x || !w || !y) return VSPW_EINVAL;
+    IgemmNT p;
+    if (!fill_fwd_params(d, p)) return VSPW_EINVAL;
+    p.src = x; p.wt = w; p.bias = bias; p.dst = y; p.stat_part = stat_part;
+    return launch_igemm_nt(p, vspw_stream(stream));
 }
 
 extern "C" int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, const float* wT, float* dx,
@@ -940,7 +983,7 @@ extern "C" int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, co
     p.m = (int)m;
     p.kdim = d->kh * d->kw * d->k;
     p.vec = (d->k % 4 == 0) ? 1 : 0;
-    return launch_igemm_nt(p, nt_pick_tile(p.m, p.nout), vspw_stream(stream));
+    return launch_igemm_nt(p, vspw_stream(stream));
 }
 
 static void wgrad_plan(const vspw_conv_desc* d, int& splits, int& chunk) {

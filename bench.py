@@ -161,6 +161,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = step(args.warmup + i)
+    host_enqueue = time.perf_counter() - t0  # host time to enqueue all K steps (GPU still running)
     barrier()
     elapsed = time.perf_counter() - t0
     ops.kernel_timer(False)
@@ -223,6 +224,7 @@ def main():
                        "parallelism": "dp%d" % world, "sync_bn": world > 1 or force},
             "e2e_mfma_frac": round(GFLOP_PER_CLIP * 1e9 * clips_per_s / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
             "last_loss": round(last_loss, 5),
+            "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

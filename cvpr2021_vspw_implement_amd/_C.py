@@ -51,7 +51,7 @@ def parse_header(path: str = HEADER):
     src = re.sub(r"//[^\n]*", "", src)
     src = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", "", src, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(int|size_t)\s+(vspw_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(int|size_t|long long)\s+(vspw_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         args = " ".join(args.split())
         if args in ("", "void"):

@@ -95,6 +95,75 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const T* __restri
     }
 }
 
+// reduce the [tiles][2][c] fp32 partials of the conv epilogue AND finalise, one workgroup per 64 channels
+__global__ __launch_bounds__(1024) void bn_finalize_partials_kernel(
+    const float* __restrict__ part, int tiles, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int c) {
+    __shared__ double red[2][16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
+    double s = 0, q = 0;
+    if (i < c)
+        for (int z = ty; z < tiles; z += 16) {
+            s += (double)part[(size_t)z * 2 * c + i];
+            q += (double)part[(size_t)z * 2 * c + c + i];
+        }
+    red[0][ty][tx] = s;
+    red[1][ty][tx] = q;
+    __syncthreads();
+    if (ty != 0 || i >= c) return;
+    s = q = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        s += red[0][j][tx];
+        q += red[1][j][tx];
+    }
+    double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0) var = 0;
+    float mf = (float)m;
+    float is = (float)(1.0 / sqrt(var + (double)eps));
+    float g = gamma ? gamma[i] : 1.f;
+    float b = beta ? beta[i] : 0.f;
+    mean[i] = mf;
+    invstd[i] = is;
+    float sc = g * is;
+    scale[i] = sc;
+    shift[i] = b - mf * sc;
+    if (rmean) rmean[i] = (1.f - momentum) * rmean[i] + momentum * mf;
+    if (rvar) {
+        double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rvar[i] = (1.f - momentum) * rvar[i] + momentum * (float)unb;
+    }
+}
+
+// sums[i] = sum_z part[z][i] (fp64) and the fp32 parameter gradients dbeta = sums[0][:], dgamma = sums[1][:]
+__global__ __launch_bounds__(1024) void reduce_partials_pg_kernel(const double* __restrict__ part,
+                                                                  double* __restrict__ sums, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta, int splits, int c) {
+    __shared__ double red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + tx;
+    const int n = 2 * c;
+    double a = 0;
+    if (col < n)
+        for (int z = ty; z < splits; z += 16) a += part[(size_t)z * n + col];
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && col < n) {
+        double v = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v += red[j][tx];
+        sums[col] = v;
+        if (col < c) {
+            if (dbeta) dbeta[col] = (float)v;
+        } else if (dgamma) {
+            dgamma[col - c] = (float)v;
+        }
+    }
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ rmean,
                                    float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
@@ -353,6 +422,17 @@ extern "C" int vspw_bn_reduce_partials_f32(const float* part, int tiles, int c, 
     return vspw_launch_status();
 }
 
+extern "C" int vspw_bn_finalize_partials_f32(const float* part, int tiles, double count, const float* gamma,
+                                             const float* beta, float* running_mean, float* running_var,
+                                             float momentum, float eps, float* mean, float* invstd, float* scale,
+                                             float* shift, int c, void* stream) {
+    if (!part || tiles <= 0 || !mean || !invstd || !scale || !shift || c <= 0 || !(count > 0)) return VSPW_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(vspw_cdiv(c, 64)), dim3(1024), 0, vspw_stream(stream), part,
+                       tiles, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                       c);
+    return vspw_launch_status();
+}
+
 extern "C" int vspw_bn_finalize(const double* sums, double count, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, float momentum, float eps, float* mean,
                                 float* invstd, float* scale, float* shift, int c, void* stream) {
@@ -386,6 +466,25 @@ extern "C" int vspw_bn_apply(const float* x, const float* scale, const float* sh
         hipLaunchKernelGGL(bn_apply_kernel<false>, dim3(vspw_stream_grid(total, 256)), dim3(256), 0,
                            vspw_stream(stream), x, scale, shift, residual, chan_mask, z, rows, c, rows_per_image, relu);
     }
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_bn_bwd_reduce_pg(const float* dz, const float* z, const float* x, const float* mean,
+                                     const float* invstd, const float* chan_mask, long long rows, int c,
+                                     long long rows_per_image, int relu, double* sums, float* dgamma, float* dbeta,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    if (!dz || !x || !mean || !invstd || !sums || rows <= 0 || c <= 0) return VSPW_EINVAL;
+    if (relu && !z) return VSPW_EINVAL;
+    if (chan_mask && rows_per_image <= 0) return VSPW_EINVAL;
+    if (rows_per_image <= 0) rows_per_image = rows;
+    int gx, gy;
+    reduce_plan(rows, c, gx, gy);
+    if (!ws || ws_bytes < (size_t)gy * 2 * c * sizeof(double)) return VSPW_EINVAL;
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(gx, gy), dim3(RED_TX, RED_TY), 0, vspw_stream(stream), dz, z, x, mean,
+                       invstd, chan_mask, rows, c, rows_per_image, relu, part);
+    hipLaunchKernelGGL(reduce_partials_pg_kernel, dim3(vspw_cdiv(2 * c, 64)), dim3(1024), 0, vspw_stream(stream), part,
+                       sums, dgamma, dbeta, gy, c);
     return vspw_launch_status();
 }
 

@@ -51,12 +51,23 @@ __global__ __launch_bounds__(CS_TX * CS_TY) void colsum_kernel(const float* __re
     }
 }
 
-__global__ void colsum_final_kernel(const double* __restrict__ part, float* __restrict__ out, int splits, int c) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= c) return;
-    double v = 0;
-    for (int z = 0; z < splits; ++z) v += part[(size_t)z * c + i];
-    out[i] = (float)v;
+// out[i] = sum_z part[z][i]: 64 columns x 16 row-lanes per workgroup
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const double* __restrict__ part, float* __restrict__ out,
+                                                            int splits, int c) {
+    __shared__ double red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + tx;
+    double a = 0;
+    if (col < c)
+        for (int z = ty; z < splits; z += 16) a += part[(size_t)z * c + col];
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && col < c) {
+        double v = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v += red[j][tx];
+        out[col] = (float)v;
+    }
 }
 
 __global__ void axpby_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, float a, float b) {
@@ -212,7 +223,7 @@ extern "C" int vspw_colsum_prod(const float* a, const float* b, float* out, long
     if (!ws || ws_bytes < (size_t)gy * c * sizeof(double)) return VSPW_EINVAL;
     double* part = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(CS_TX, CS_TY), 0, vspw_stream(stream), a, b, rows, c, part);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(vspw_cdiv(c, 256)), dim3(256), 0, vspw_stream(stream), part, out, gy,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(vspw_cdiv(c, 64)), dim3(1024), 0, vspw_stream(stream), part, out, gy,
                        c);
     return vspw_launch_status();
 }
@@ -308,5 +319,53 @@ extern "C" int vspw_sgd_step(float* p, const float* g, float* buf, long long n, 
     if (!p || !g || !buf || n <= 0 || mult <= 0) return VSPW_EINVAL;
     hipLaunchKernelGGL(sgd_step_kernel, dim3(vspw_stream_grid(n, 256)), dim3(256), 0, vspw_stream(stream), p, g, buf,
                        n, lr, wd, momentum, mult, first);
+    return vspw_launch_status();
+}
+
+
+// ---- multi-tensor SGD: one launch updates every parameter of the model -------------------------------------------
+// entries[] (device) is sorted by chunk0; workgroup b finds its tensor by binary search and updates one 16384-element
+// chunk of it with the same arithmetic as sgd_step_kernel.
+#define SGD_CHUNK 16384
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const vspw_sgd_entry* __restrict__ entries, int n_entries,
+                                                        float momentum) {
+    const long long b = blockIdx.x;
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (entries[mid].chunk0 <= b)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const vspw_sgd_entry e = entries[lo];
+    const long long begin = (b - e.chunk0) * SGD_CHUNK;
+    const long long end = min(e.n, begin + SGD_CHUNK);
+    float* __restrict__ p = e.p;
+    const float* __restrict__ g = e.g;
+    float* __restrict__ buf = e.buf;
+    for (long long i = begin + threadIdx.x; i < end; i += blockDim.x) {
+        float pv = p[i];
+        const float gv = g[i];
+        float bv = e.first ? 0.f : buf[i];
+        bool have = !e.first;
+        for (int r = 0; r < e.mult; ++r) {
+            const float d = gv + e.wd * pv;
+            bv = have ? momentum * bv + d : d;
+            have = true;
+            pv -= e.lr * bv;
+        }
+        p[i] = pv;
+        buf[i] = bv;
+    }
+}
+
+extern "C" long long vspw_sgd_chunk_elems(void) { return SGD_CHUNK; }
+
+extern "C" int vspw_sgd_multi(const vspw_sgd_entry* entries, int n_entries, long long total_chunks, float momentum,
+                              void* stream) {
+    if (!entries || n_entries <= 0 || total_chunks <= 0 || total_chunks > 0x7fffffffLL) return VSPW_EINVAL;
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, vspw_stream(stream), entries,
+                       n_entries, momentum);
     return vspw_launch_status();
 }

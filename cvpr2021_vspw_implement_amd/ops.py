@@ -287,14 +287,11 @@ class BatchNormActFn(torch.autograd.Function):
         nbytes = _C.query("vspw_bn_bwd_workspace", rows, c)
         ws = _ws(nbytes, dev)
         relu = 1 if ctx.relu else 0
-        _C.call("vspw_bn_bwd_reduce", _p(dz), _p(z), _p(x), _p(mean), _p(invstd), _p(mask), rows, c, h * w, relu,
-                _p(sums), _p(ws), nbytes, st)
         dgamma = torch.empty(c, device=dev, dtype=torch.float32) if ctx.needs_input_grad[1] else None
         dbeta = torch.empty(c, device=dev, dtype=torch.float32) if ctx.needs_input_grad[2] else None
-        if dgamma is not None or dbeta is not None:  # parameter gradients are the LOCAL sums
-            _C.call("vspw_bn_bwd_apply", _p(dz), _p(z), _p(x), _p(mean), _p(invstd), _p(gamma), _p(sums),
-                    ctypes.c_double(ctx.count), _p(mask), rows, c, h * w, relu, 1 if ctx.training else 0, None, None,
-                    _p(dgamma), _p(dbeta), st)
+        # reduction + the LOCAL parameter gradients (taken before any cross-rank exchange)
+        _C.call("vspw_bn_bwd_reduce_pg", _p(dz), _p(z), _p(x), _p(mean), _p(invstd), _p(mask), rows, c, h * w, relu,
+                _p(sums), _p(dgamma), _p(dbeta), _p(ws), nbytes, st)
         if ctx.training and ctx.world != 1:
             _all_reduce_sums(sums)
         dx = empty_nhwc(n, c, h, w, dev) if ctx.needs_input_grad[0] else None
@@ -335,19 +332,24 @@ class ConvBNActFn(torch.autograd.Function):
             if rows * max(_sync_world(), 1) <= 1:
                 raise ValueError("Expected more than 1 value per channel when training, got input size %s"
                                  % (tuple(y.shape),))
-            sums = torch.empty((2, c), device=dev, dtype=torch.float64)
-            if part is not None:
-                _C.call("vspw_bn_reduce_partials_f32", _p(part), part.shape[0], c, _p(sums), st)
-            else:
-                nbytes = _C.query("vspw_bn_stats_workspace", rows, c)
-                ws = _ws(nbytes, dev)
-                _C.call("vspw_bn_stats", _p(y), rows, c, _p(sums), _p(ws), nbytes, st)
             world = _sync_world()
-            if world != 1:
-                _all_reduce_sums(sums)
-                count = float(rows * max(world, 1))
-            _C.call("vspw_bn_finalize", _p(sums), ctypes.c_double(count), _p(gamma), _p(beta), _p(running_mean),
-                    _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), c, st)
+            if part is not None and world == 1:  # single rank: reduce the epilogue partials and finalise in one launch
+                _C.call("vspw_bn_finalize_partials_f32", _p(part), part.shape[0], ctypes.c_double(count), _p(gamma),
+                        _p(beta), _p(running_mean), _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale),
+                        _p(shift), c, st)
+            else:
+                sums = torch.empty((2, c), device=dev, dtype=torch.float64)
+                if part is not None:
+                    _C.call("vspw_bn_reduce_partials_f32", _p(part), part.shape[0], c, _p(sums), st)
+                else:
+                    nbytes = _C.query("vspw_bn_stats_workspace", rows, c)
+                    ws = _ws(nbytes, dev)
+                    _C.call("vspw_bn_stats", _p(y), rows, c, _p(sums), _p(ws), nbytes, st)
+                if world != 1:
+                    _all_reduce_sums(sums)
+                    count = float(rows * max(world, 1))
+                _C.call("vspw_bn_finalize", _p(sums), ctypes.c_double(count), _p(gamma), _p(beta), _p(running_mean),
+                        _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), c, st)
         else:
             _C.call("vspw_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(mean),
                     _p(invstd), _p(scale), _p(shift), c, st)
@@ -381,14 +383,11 @@ class ConvBNActFn(torch.autograd.Function):
         sums = torch.empty((2, c), device=dev, dtype=torch.float64)
         nbytes = _C.query("vspw_bn_bwd_workspace", rows, c)
         ws = _ws(nbytes, dev)
-        _C.call("vspw_bn_bwd_reduce", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(mask), rows, c, h * wd, relu,
-                _p(sums), _p(ws), nbytes, st)
         dgamma = torch.empty(c, device=dev, dtype=torch.float32) if ctx.needs_input_grad[3] else None
         dbeta = torch.empty(c, device=dev, dtype=torch.float32) if ctx.needs_input_grad[4] else None
-        if dgamma is not None or dbeta is not None:
-            _C.call("vspw_bn_bwd_apply", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums),
-                    ctypes.c_double(ctx.count), _p(mask), rows, c, h * wd, relu, train, None, None, _p(dgamma),
-                    _p(dbeta), st)
+        # reduction + the LOCAL parameter gradients (dgamma/dbeta are taken before any cross-rank exchange)
+        _C.call("vspw_bn_bwd_reduce_pg", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(mask), rows, c, h * wd, relu,
+                _p(sums), _p(dgamma), _p(dbeta), _p(ws), nbytes, st)
         if ctx.training and ctx.world != 1:
             _all_reduce_sums(sums)
         dy = empty_nhwc(n, c, h, wd, dev)

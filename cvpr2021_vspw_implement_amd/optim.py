@@ -8,9 +8,14 @@ but folds the k occurrences of a parameter into ONE kernel launch that applies t
 import ctypes
 from collections import OrderedDict
 
+import numpy as np
 import torch
 
 from . import _C
+
+# struct vspw_sgd_entry (include/vspw_hip.h)
+_ENTRY = np.dtype([("p", "<u8"), ("g", "<u8"), ("buf", "<u8"), ("n", "<i8"), ("chunk0", "<i8"), ("lr", "<f4"),
+                   ("wd", "<f4"), ("mult", "<i4"), ("first", "<i4")])
 
 
 class SGD(torch.optim.Optimizer):
@@ -31,10 +36,13 @@ class SGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        """One multi-tensor launch (vspw_sgd_multi) updates every parameter; per-parameter records (pointers, size,
+        lr, weight decay, multiplicity) are rebuilt each step because autograd hands out fresh gradient tensors."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        by_mom = {}
         for group in self.param_groups:
             lr, wd, mom = float(group["lr"]), float(group["weight_decay"]), float(group["momentum"])
             for p, mult in zip(group["params"], group["mult"]):
@@ -49,10 +57,19 @@ class SGD(torch.optim.Optimizer):
                 first = "momentum_buffer" not in st
                 if first:
                     st["momentum_buffer"] = torch.empty_like(p)
-                buf = st["momentum_buffer"]
-                _C.call("vspw_sgd_step", ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(g.data_ptr()),
-                        ctypes.c_void_p(buf.data_ptr()), p.numel(), lr, wd, mom, int(mult), 1 if first else 0,
-                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                by_mom.setdefault((mom, p.device), []).append((p, g, st["momentum_buffer"], lr, wd, int(mult), first))
+        chunk = int(_C.query("vspw_sgd_chunk_elems"))
+        for (mom, dev), items in by_mom.items():
+            rec = np.zeros(len(items), dtype=_ENTRY)
+            c0 = 0
+            for i, (p, g, buf, lr, wd, mult, first) in enumerate(items):
+                n = p.numel()
+                rec[i] = (p.data_ptr(), g.data_ptr(), buf.data_ptr(), n, c0, lr, wd, mult, 1 if first else 0)
+                c0 += (n + chunk - 1) // chunk
+            table = torch.from_numpy(rec.view(np.uint8)).to(dev, non_blocking=True)
+            _C.call("vspw_sgd_multi", ctypes.c_void_p(table.data_ptr()), len(items), c0, mom,
+                    ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            self._keepalive = (table, items)  # until the next step: the launch is asynchronous
         return loss
 
 

@@ -75,6 +75,10 @@ int vspw_bn_reduce_partials_f32(const float* part, int tiles, int c, double* sum
 int vspw_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                      float* shift, int c, void* stream);
+/* vspw_bn_reduce_partials_f32 + vspw_bn_finalize in one launch (single-rank training: no exchange in between). */
+int vspw_bn_finalize_partials_f32(const float* part, int tiles, double count, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                  float* invstd, float* scale, float* shift, int c, void* stream);
 /* Eval-mode coefficients from the running statistics. */
 int vspw_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float eps, float* mean, float* invstd, float* scale, float* shift, int c, void* stream);
@@ -87,6 +91,11 @@ size_t vspw_bn_bwd_workspace(long long rows, int c);
 int vspw_bn_bwd_reduce(const float* dz, const float* z, const float* x, const float* mean, const float* invstd,
                        const float* chan_mask, long long rows, int c, long long rows_per_image, int relu,
                        double* sums, void* ws, size_t ws_bytes, void* stream);
+/* Same, additionally writing dbeta = sums[0], dgamma = sums[1] as fp32 (the LOCAL parameter gradients); either may be
+ * NULL. */
+int vspw_bn_bwd_reduce_pg(const float* dz, const float* z, const float* x, const float* mean, const float* invstd,
+                          const float* chan_mask, long long rows, int c, long long rows_per_image, int relu,
+                          double* sums, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
 /* dx = gamma*invstd*(g - sums0/count - xhat*sums1/count) (training) or gamma*invstd*g (eval);
  * dres = g (optional); dgamma = sums1, dbeta = sums0 (as fp32). */
 int vspw_bn_bwd_apply(const float* dz, const float* z, const float* x, const float* mean, const float* invstd,
@@ -191,6 +200,20 @@ int vspw_flowwarp_bwd(const float* dy, const float* x, const float* flow, float*
  * models/clip_psp.py:99-135).  p, g, buf are dense tensors with identical strides; first != 0 initialises buf. */
 int vspw_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float wd, float momentum, int mult,
                   int first, void* stream);
+/* The same update for EVERY parameter in one launch.  `entries` is a DEVICE array of n_entries records sorted by
+ * chunk0 (chunk0 = number of vspw_sgd_chunk_elems()-sized chunks of all preceding tensors); total_chunks = grid size. */
+typedef struct vspw_sgd_entry {
+    float* p;
+    const float* g;
+    float* buf;
+    long long n;
+    long long chunk0;
+    float lr, wd;
+    int mult, first;
+} vspw_sgd_entry;
+long long vspw_sgd_chunk_elems(void);
+int vspw_sgd_multi(const vspw_sgd_entry* entries, int n_entries, long long total_chunks, float momentum,
+                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -370,3 +370,42 @@ def test_flowwarp_and_blend(dev):
     _close(od, out, 1e-6, "blend fwd")
     for a, r in zip(dl, leaves):
         _close(a.grad, r.grad, 2e-5, "blend bwd")
+
+
+def test_sgd_matches_loop_semantics_with_duplicate_params(dev):
+    """vspw SGD == torch.optim.SGD(1.3.1) applied as a Python loop over the reference's parameter-group listings,
+    which contain each parameter once per enclosing module (train_clip2.py:215-236 + models/clip_psp.py:99-135)."""
+    from cvpr2021_vspw_implement_amd import optim
+
+    g = torch.Generator().manual_seed(77)
+    shapes = [(64, 3, 3, 3), (64,), (70000,), (5, 7), (128, 64, 1, 1)]
+    mults = [4, 2, 1, 3, 4]
+    base = [torch.randn(s, generator=g) for s in shapes]
+    grads = [[torch.randn(s, generator=g) for s in shapes] for _ in range(3)]
+    lr, wd, mom = 0.02, 1e-4, 0.9
+
+    # reference: loop semantics on CPU
+    ref = [b.clone() for b in base]
+    bufs = [None] * len(ref)
+    for step in range(3):
+        for i, p in enumerate(ref):
+            this_wd = wd if i % 2 == 0 else 0.0
+            this_lr = lr * (0.1 if i < 2 else 1.0)
+            for _ in range(mults[i]):
+                d = grads[step][i] + this_wd * p
+                bufs[i] = d.clone() if bufs[i] is None else bufs[i] * mom + d
+                p -= this_lr * bufs[i]
+
+    params = [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+    params[0].data = params[0].data.contiguous(memory_format=torch.channels_last)
+    groups = []
+    for i, p in enumerate(params):
+        groups.append({"params": [p] * mults[i], "lr": lr * (0.1 if i < 2 else 1.0),
+                       "weight_decay": wd if i % 2 == 0 else 0.0})
+    opt = optim.SGD(groups, lr=lr, momentum=mom, weight_decay=wd)
+    for step in range(3):
+        for i, p in enumerate(params):
+            p.grad = grads[step][i].to(dev)
+        opt.step()
+    for p, r in zip(params, ref):
+        _close(p, r, 2e-6, "sgd param")

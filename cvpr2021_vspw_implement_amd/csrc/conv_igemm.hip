@@ -741,10 +741,13 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(IgemmTN p) {
 // igemm_nt_v2_kernel — two LDS buffers, one barrier per 32-pixel K-tile, straight-line loop body with clamped
 // always-valid addresses (zeroing applied when the registers are written to LDS), next-next tile's global loads issued
 // in the shadow of the MFMAs.
-template <bool WIDE>
+#ifndef TN_NBUF
+#define TN_NBUF 1
+#endif
+template <bool WIDE, int NBUF>
 __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
-    __shared__ __attribute__((aligned(16))) float As[2][BK * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+    __shared__ __attribute__((aligned(16))) float As[NBUF][BK * BM];
+    __shared__ __attribute__((aligned(16))) float Bs[NBUF][BK * BN];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -844,13 +847,20 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     const int nk = (p_end - p_begin + BK - 1) / BK;
     if (nk > 0) {
         load_tile();
-        store_tile(As[0], Bs[0]);
-        advance();
-        load_tile();  // rows past p_end are zeroed at store time
-        __syncthreads();
+        if (NBUF == 2) {
+            store_tile(As[0], Bs[0]);
+            advance();
+            load_tile();  // rows past p_end are zeroed at store time
+            __syncthreads();
+        }
     }
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+        const int cur = (NBUF == 2) ? (kt & 1) : 0;
+        if (NBUF == 1) {
+            store_tile(As[0], Bs[0]);
+            __syncthreads();
+            advance();
+        }
         const float* Ac = As[cur];
         const float* Bc = Bs[cur];
 #pragma unroll
@@ -867,9 +877,11 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             if (s == 3) {
-                store_tile(As[cur ^ 1], Bs[cur ^ 1]);  // tile kt+1 (in flight since the previous iteration)
-                advance();
-                load_tile();                           // tile kt+2 gets a whole iteration to land
+                if (NBUF == 2) {
+                    store_tile(As[(NBUF - 1) & (cur ^ 1)], Bs[(NBUF - 1) & (cur ^ 1)]);  // tile kt+1
+                    advance();
+                }
+                load_tile();  // NBUF 2: tile kt+2 (a whole iteration to land); NBUF 1: tile kt+1
             }
         }
         __syncthreads();
@@ -995,7 +1007,7 @@ static void wgrad_plan(const vspw_conv_desc* d, int& splits, int& chunk) {
     long long P = (long long)d->n * d->oh * d->ow;
     int ncols = d->kh * d->kw * d->c;
     long long tiles = (long long)vspw_cdiv(d->k, BM) * vspw_cdiv(ncols, BN);
-    long long want = (1024 + tiles / 2) / tiles;  // ~4 workgroups per CU (2 resident) keeps the tail short
+    long long want = (768 + tiles / 2) / tiles;  // 3 workgroups per CU, all resident at once (single LDS buffer)
     long long max_splits = (P + 255) / 256;
     if (want > max_splits) want = max_splits;
     if (want < 1) want = 1;
@@ -1039,9 +1051,9 @@ extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, 
     const bool v2 = p.vec_a && p.vec_b && (long long)p.P * p.k < 0x7fffffffLL &&
                     (long long)d->n * d->h * d->w * d->c < 0x7fffffffLL;
     if (v2 && p.ow >= BK)
-        hipLaunchKernelGGL(igemm_tn_v2_kernel<true>, dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
+        hipLaunchKernelGGL((igemm_tn_v2_kernel<true, TN_NBUF>), dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
     else if (v2)
-        hipLaunchKernelGGL(igemm_tn_v2_kernel<false>, dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
+        hipLaunchKernelGGL((igemm_tn_v2_kernel<false, 2>), dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
     else
         hipLaunchKernelGGL(igemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
     int st = vspw_launch_status();

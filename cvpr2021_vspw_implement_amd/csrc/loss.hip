@@ -329,23 +329,43 @@ __global__ __launch_bounds__(256) void upsample_softmax_kernel(const float* __re
         const float* p01 = logits + (((size_t)img * h + y0) * w + x1) * k;
         const float* p10 = logits + (((size_t)img * h + y1) * w + x0) * k;
         const float* p11 = logits + (((size_t)img * h + y1) * w + x1) * k;
-        float m = -INFINITY;
-        for (int j = lane; j < k; j += 64) {
-            const float v = hy * (hx * p00[j] + lx * p01[j]) + ly * (hx * p10[j] + lx * p11[j]);
-            m = fmaxf(m, v);
-        }
-        m = wave_max(m);
-        float s = 0.f;
-        for (int j = lane; j < k; j += 64) {
-            const float v = hy * (hx * p00[j] + lx * p01[j]) + ly * (hx * p10[j] + lx * p11[j]);
-            s += expf(v - m);
-        }
-        s = wave_sum(s);
-        const float inv = 1.f / s;
         float* dst = probs + (size_t)pix * k;
-        for (int j = lane; j < k; j += 64) {
-            const float v = hy * (hx * p00[j] + lx * p01[j]) + ly * (hx * p10[j] + lx * p11[j]);
-            dst[j] = expf(v - m) * inv;
+        if (k <= 256) {
+            // interpolate once, keep the (at most 4) values of this lane in registers: the three softmax passes then
+            // see bit-identical inputs (re-evaluating the blend may contract differently and, for huge logits, break
+            // max >= v)
+            float vals[4];
+            float m = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int j = lane + 64 * t;
+                vals[t] = (j < k) ? hy * (hx * p00[j] + lx * p01[j]) + ly * (hx * p10[j] + lx * p11[j]) : -INFINITY;
+                m = fmaxf(m, vals[t]);
+            }
+            m = wave_max(m);
+            float s = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                vals[t] = (lane + 64 * t < k) ? expf(vals[t] - m) : 0.f;
+                s += vals[t];
+            }
+            s = wave_sum(s);
+            const float inv = 1.f / s;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (lane + 64 * t < k) dst[lane + 64 * t] = vals[t] * inv;
+        } else {
+            float m = -INFINITY;
+            for (int j = lane; j < k; j += 64)
+                m = fmaxf(m, hy * (hx * p00[j] + lx * p01[j]) + ly * (hx * p10[j] + lx * p11[j]));
+            m = wave_max(m);
+            float s = 0.f;
+            for (int j = lane; j < k; j += 64)
+                s += expf(fminf(hy * (hx * p00[j] + lx * p01[j]) + ly * (hx * p10[j] + lx * p11[j]) - m, 0.f));
+            s = wave_sum(s);
+            const float inv = 1.f / s;
+            for (int j = lane; j < k; j += 64)
+                dst[j] = expf(fminf(hy * (hx * p00[j] + lx * p01[j]) + ly * (hx * p10[j] + lx * p11[j]) - m, 0.f)) * inv;
         }
     }
 }

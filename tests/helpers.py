@@ -125,3 +125,16 @@ def logit_tol(fx, floor=1e-3):
     if "eval_logits64" in fx.files:
         return max(floor, 4.0 * float(np.abs(fx["eval_logits"] - fx["eval_logits64"]).max()))
     return floor
+
+
+def calibrate_bn_hip(module, run_train_forward):
+    """Same recipe as tools/make_golden.py:calibrate_bn, on the HIP modules: one training-mode forward with momentum 1
+    sets every running statistic to the batch statistic, so that eval mode is meaningful with random weights."""
+    bns = [m for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    for m in bns:
+        m.momentum = 1.0
+    module.train()
+    with torch.no_grad():
+        run_train_forward()
+    for m in bns:
+        m.momentum = 0.1

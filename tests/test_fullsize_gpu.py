@@ -1,0 +1,131 @@
+"""BASELINE.json configurations at their full sizes on the MI355X.
+cfg 1 (resnet18dilated + ppm_deepsup, one 480x853 frame) is small enough for the numpy oracle to be evaluated live and
+compared value by value; the larger configurations are checked through size-independent properties (probabilities
+normalised, finite loss ~ log K at random init, finite gradients on every parameter, loss linear in the incoming
+gradient, eval deterministic)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import K, build, calibrate_bn_hip, load_det, zero_dropout
+from oracle.det_init import det_input, det_labels
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_cfg1_r18_ppm_480p_frame_against_oracle(dev):
+    from oracle import np_models as NM
+    from oracle import np_ops as O
+
+    O.set_dtype(np.float32)
+    mod = build("seg", "resnet18dilated", "ppm_deepsup", 512)
+    sd = load_det(mod)
+    mod.to(dev).eval()
+    img = det_input("cfg1", (1, 3, 480, 853))
+    store = {}
+    h = mod.decoder.conv_last_.register_forward_hook(lambda m, i, o: store.__setitem__("l", o.float().cpu().numpy()))
+    with torch.no_grad():
+        probs = mod({"img_data": _t(img, dev), "seg_label": torch.zeros(1, 1, 480, 853, device=dev)},
+                    segSize=(480, 853))
+    h.remove()
+    assert tuple(probs.shape) == (1, K, 480, 853)
+    P = NM.Params({k: v.copy() for k, v in sd.items()}, train_params=False)
+    feats = NM.resnet_dilated(P, O.Var(img), "resnet18", "encoder.", False)
+    conv5 = feats[-1]
+    pooled = [O.adaptive_avg_pool2d(conv5, s) for s in (1, 2, 3, 6)]  # 60x107 map: overlapping bins
+    logits = NM._head(P, NM._ppm_concat(P, conv5, pooled, "decoder.ppm.", 1, 2, False), "decoder.conv_last_", False)
+    assert logits.shape == store["l"].shape == (1, K, 60, 107)
+    err = np.abs(store["l"] - logits.v).max()
+    assert err < 1e-3, err
+    ref = O.softmax(O.interpolate_bilinear(logits, (480, 853)), 1).v
+    got = probs.float().cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-3
+    s = np.sort(ref, axis=1)
+    decisive = (np.log(s[:, -1]) - np.log(s[:, -2])) > 2e-3
+    assert ((got.argmax(1) != ref.argmax(1)) & decisive).sum() == 0
+    assert np.abs(got.sum(1) - 1).max() < 1e-5
+
+
+def test_cfg2_r101_ppm_480p_frame_properties(dev):
+    mod = build("seg", "resnet101dilated", "ppm_deepsup", 2048)
+    load_det(mod)
+    mod.to(dev)
+    img = _t(det_input("cfg2", (1, 3, 480, 853)), dev)
+    two = torch.cat([img, img.flip(-1)], 0)
+    lab2 = _t(det_labels("cfg2", (2, 1, 480, 853), K), dev)
+    calibrate_bn_hip(mod, lambda: mod({"img_data": two, "seg_label": lab2}))
+    mod.eval()
+    with torch.no_grad():
+        p1 = mod({"img_data": img, "seg_label": torch.zeros(1, 1, 480, 853, device=dev)}, segSize=(480, 853))
+        p2 = mod({"img_data": img, "seg_label": torch.zeros(1, 1, 480, 853, device=dev)}, segSize=(480, 853))
+    assert tuple(p1.shape) == (1, K, 480, 853)
+    assert torch.isfinite(p1).all() and (p1 >= 0).all()
+    assert (p1.sum(1) - 1).abs().max().item() < 1e-5
+    assert torch.equal(p1, p2), "inference is deterministic"
+    assert p1.max().item() < 0.999, "calibrated BN statistics keep the random-weight logits in a sane range"
+
+
+@pytest.mark.parametrize("kind", ["clip_ocr"])
+def test_cfg4_tcb_ocr_train_step_properties(dev, kind):
+    mod = build(kind, "resnet101dilated").to(dev)
+    mod.train()
+    zero_dropout(mod)
+    g = torch.Generator().manual_seed(304)
+    T, B, S = 5, 2, 479
+    imgs = [torch.randn(B, 3, S, S, generator=g).to(dev) for _ in range(T)]
+    labs = [torch.randint(0, K, (B, 1, S, S), generator=g).float().to(dev) for _ in range(T)]
+
+    def step(scale):
+        mod.zero_grad()
+        loss, acc = mod({"img_data": imgs[-1], "seg_label": labs[-1], "clipimgs_data": list(imgs[:-1]),
+                         "cliplabels_data": list(labs[:-1])})
+        (loss * scale).backward()
+        return loss.item(), {k: p.grad.norm().item() for k, p in mod.named_parameters()}
+
+    l1, g1 = step(1.0)
+    l2, g2 = step(2.0)
+    assert math.isfinite(l1) and abs(l1 - l2) < 1e-5 * abs(l1)
+    assert 0.5 * 1.4 * math.log(K) < l1 < 3 * 1.4 * math.log(K)
+    gmax = max(g2.values())
+    for k in g1:
+        assert math.isfinite(g1[k]), k
+        # conv biases in front of a train-mode BN have an exactly-zero gradient (pure rounding noise): absolute floor
+        assert abs(g2[k] - 2 * g1[k]) <= 1e-3 * max(g2[k], 1e-6 * gmax), k
+
+
+def test_cfg5_nonlocal3d_t7_and_netwarp_fullsize_properties(dev):
+    """cfg 5 pieces: Non_local3d over T=7 frames (N = 7*60*60 = 25 200 positions, a 2.5 GB affinity per sample) and
+    NetWarp (R101, T=2) with a synthetic flow field, at 479x479."""
+    S = 479
+    g = torch.Generator().manual_seed(5)
+    mod = build("nonlocal3d", "resnet101dilated").to(dev)
+    mod.train()
+    imgs = [torch.randn(1, 3, S, S, generator=g).to(dev) for _ in range(7)]
+    labs = [torch.randint(0, K, (1, 1, S, S), generator=g).float().to(dev) for _ in range(7)]
+    loss, acc = mod({"clipimgs_data": imgs, "cliplabels_data": labs})
+    loss.backward()
+    assert math.isfinite(loss.item())
+    assert all(torch.isfinite(p.grad).all() for p in mod.parameters() if p.grad is not None)
+    assert mod.nonlocalblock.theta.weight.grad is not None
+    del mod, loss
+    torch.cuda.empty_cache()
+
+    class Flow(torch.nn.Module):
+        def forward(self, a, b, iters=20, test_mode=True):
+            n, _, h, w = a.shape
+            return None, (torch.randn(n, 2, h, w, device=a.device) * 1.9 - 0.7).clamp(-10, 10)
+
+    nw = build("netwarp", "resnet101dilated", flow_net=Flow()).to(dev)
+    nw.train()
+    cur, prev = torch.randn(2, 3, S, S, generator=g).to(dev), torch.randn(2, 3, S, S, generator=g).to(dev)
+    lab = torch.randint(0, K, (2, 1, S, S), generator=g).float().to(dev)
+    loss, acc = nw({"img_data": cur, "seg_label": lab, "clipimgs_data": [prev], "cliplabels_data": []})
+    loss.backward()
+    assert math.isfinite(loss.item())
+    assert torch.isfinite(nw.w0_1.grad).all() and torch.isfinite(nw.flowcnn.conv1[0].weight.grad).all()

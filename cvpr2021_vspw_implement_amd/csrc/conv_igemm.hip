@@ -903,13 +903,34 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     }
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, long long n, int splits) {
+// dW = sum over split-K partial slabs (fixed order: deterministic).  float4 lanes, 4 slabs in flight per step.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                            long long n, int splits) {
+    const long long n4 = (n & 3) ? 0 : (n >> 2);  // slabs are 16-B aligned only when n % 4 == 0
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
+    for (; i < n4; i += stride) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 4 <= splits; z += 4) {
+            const f32x4 a = p4[(size_t)z * n4 + i];
+            const f32x4 b = p4[(size_t)(z + 1) * n4 + i];
+            const f32x4 c = p4[(size_t)(z + 2) * n4 + i];
+            const f32x4 d = p4[(size_t)(z + 3) * n4 + i];
+            s += a;
+            s += b;
+            s += c;
+            s += d;
+        }
+        for (; z < splits; ++z) s += p4[(size_t)z * n4 + i];
+        reinterpret_cast<f32x4*>(out)[i] = s;
+    }
+    // scalar path: everything when n % 4 != 0, nothing otherwise
+    for (long long j = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
         float s = 0.f;
-        for (int z = 0; z < splits; ++z) s += part[(size_t)z * n + i];
-        out[i] = s;
+        for (int z = 0; z < splits; ++z) s += part[(size_t)z * n + j];
+        out[j] = s;
     }
 }
 
@@ -1060,7 +1081,7 @@ extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, 
     if (st != VSPW_OK) return st;
     if (splits > 1) {
         long long n = (long long)p.k * p.ncols;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(vspw_stream_grid(n, 256)), dim3(256), 0, vspw_stream(stream),
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(vspw_stream_grid(n / 4 + 1, 256)), dim3(256), 0, vspw_stream(stream),
                            reinterpret_cast<const float*>(ws), dw, n, splits);
         st = vspw_launch_status();
     }

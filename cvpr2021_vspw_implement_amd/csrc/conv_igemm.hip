@@ -744,10 +744,17 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(IgemmTN p) {
 #ifndef TN_NBUF
 #define TN_NBUF 1
 #endif
-template <bool WIDE, int NBUF>
+// WM / WN = MFMA 32x32 blocks per wave along Cout / along (tap, Cin); 2x2 waves -> tile (64*WM) x (64*WN).
+// Narrow weight matrices (Cout <= 64 or KH*KW*Cin <= 64: the stem, layer1, 1x1 convs to/from 64 channels) use
+// WM = 1 / WN = 1 so that no half of the MFMA tile is spent on padding.
+template <bool WIDE, int NBUF, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
-    __shared__ __attribute__((aligned(16))) float As[NBUF][BK * BM];
-    __shared__ __attribute__((aligned(16))) float Bs[NBUF][BK * BN];
+    constexpr int TM = 64 * WM, TN = 64 * WN;
+    constexpr int A4 = TM / 4, B4 = TN / 4;          // float4 per staged row
+    constexpr int RPA = 256 / A4, RPB = 256 / B4;    // rows covered per pass
+    constexpr int PA = BK / RPA, PB = BK / RPB;      // passes (float4 per thread) = 2 or 4
+    __shared__ __attribute__((aligned(16))) float As[NBUF][BK * TM];
+    __shared__ __attribute__((aligned(16))) float Bs[NBUF][BK * TN];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -755,21 +762,21 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    const int tiles_n = (p.ncols + BN - 1) / BN;
+    const int tiles_n = (p.ncols + TN - 1) / TN;
     const int tile_n = blockIdx.x % tiles_n;
     const int tile_m = blockIdx.x / tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * TM, n0 = tile_n * TN;
     const int split = blockIdx.y;
     const int p_begin = split * p.chunk;
     const int p_end = min(p.P, p_begin + p.chunk);
 
-    const int krow = tid >> 5;
-    const int c4 = (tid & 31) * 4;
+    const int krow_a = tid / A4, ca4 = (tid % A4) * 4;
+    const int krow_b = tid / B4, cb4 = (tid % B4) * 4;
 
     // this thread's A column (co) and B column (tap, ci): fixed for the whole kernel
-    const int co = m0 + c4;
+    const int co = m0 + ca4;
     const bool a_colok = co < p.k;
-    const int ncol = n0 + c4;
+    const int ncol = n0 + cb4;
     const bool b_colok = ncol < p.ncols;
     int b_ci, b_dy, b_dx;
     {
@@ -783,21 +790,23 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     }
     const int ohw = p.oh * p.ow;
 
-    // pixel state of the 4 rows this thread stages: (image, oy, ox) advance by BK pixels per K-tile.  When the row
-    // is at least BK wide the update is a compare/select chain; otherwise fall back to two integer divisions.
-    int r_pp[4], r_n[4], r_oy[4], r_ox[4];
+    // pixel state of the PB rows this thread stages for B: (image, oy, ox) advance by BK pixels per K-tile.  When the
+    // row is at least BK wide the update is a compare/select chain; otherwise two integer divisions.  A only needs
+    // the linear pixel index.
+    int pk0 = p_begin;
+    int r_n[PB], r_oy[PB], r_ox[PB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        r_pp[i] = p_begin + krow + 8 * i;
-        r_n[i] = r_pp[i] / ohw;
-        const int r = r_pp[i] - r_n[i] * ohw;
+    for (int i = 0; i < PB; ++i) {
+        const int pp = p_begin + krow_b + RPB * i;
+        r_n[i] = pp / ohw;
+        const int r = pp - r_n[i] * ohw;
         r_oy[i] = r / p.ow;
         r_ox[i] = r - r_oy[i] * p.ow;
     }
     auto advance = [&]() {
+        pk0 += BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            r_pp[i] += BK;
+        for (int i = 0; i < PB; ++i) {
             if (WIDE) {  // ow >= BK: at most one row wrap per step
                 r_ox[i] += BK;
                 const bool wx = r_ox[i] >= p.ow;
@@ -807,21 +816,26 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
                 r_oy[i] = wy ? 0 : r_oy[i];
                 r_n[i] = wy ? r_n[i] + 1 : r_n[i];
             } else {
-                r_n[i] = r_pp[i] / ohw;
-                const int r = r_pp[i] - r_n[i] * ohw;
+                const int pp = pk0 + krow_b + RPB * i;
+                r_n[i] = pp / ohw;
+                const int r = pp - r_n[i] * ohw;
                 r_oy[i] = r / p.ow;
                 r_ox[i] = r - r_oy[i] * p.ow;
             }
         }
     };
-    f32x4 ra[4], rb[4];
-    bool oka[4], okb[4];
+    f32x4 ra[PA], rb[PB];
+    bool oka[PA], okb[PB];
     auto load_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool pin = r_pp[i] < p_end;
-            oka[i] = pin & a_colok;
-            ra[i] = *reinterpret_cast<const f32x4*>(p.dy + (oka[i] ? r_pp[i] * p.k + co : 0));
+        for (int i = 0; i < PA; ++i) {
+            const int pp = pk0 + krow_a + RPA * i;
+            oka[i] = (pp < p_end) & a_colok;
+            ra[i] = *reinterpret_cast<const f32x4*>(p.dy + (oka[i] ? pp * p.k + co : 0));
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const bool pin = (pk0 + krow_b + RPB * i) < p_end;
             const int sy = r_oy[i] * p.stride + b_dy, sx = r_ox[i] * p.stride + b_dx;
             okb[i] = pin & b_colok & ((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w);
             rb[i] = *reinterpret_cast<const f32x4*>(p.x + (okb[i] ? ((r_n[i] * p.h + sy) * p.w + sx) * p.c + b_ci : 0));
@@ -830,17 +844,18 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto store_tile = [&](float* Ad, float* Bd) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(&Ad[(krow + 8 * i) * BM + c4]) = oka[i] ? ra[i] : zero4;
-            *reinterpret_cast<f32x4*>(&Bd[(krow + 8 * i) * BN + c4]) = okb[i] ? rb[i] : zero4;
-        }
+        for (int i = 0; i < PA; ++i)
+            *reinterpret_cast<f32x4*>(&Ad[(krow_a + RPA * i) * TM + ca4]) = oka[i] ? ra[i] : zero4;
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            *reinterpret_cast<f32x4*>(&Bd[(krow_b + RPB * i) * TN + cb4]) = okb[i] ? rb[i] : zero4;
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[WM][WN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -865,16 +880,15 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
         const float* Bc = Bs[cur];
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
-            float a[2], b[2];
+            float a[WM], b[WN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = Ac[(2 * s + lh) * BM + wm * 64 + i * 32 + l31];
-                b[i] = Bc[(2 * s + lh) * BN + wn * 64 + i * 32 + l31];
-            }
+            for (int i = 0; i < WM; ++i) a[i] = Ac[(2 * s + lh) * TM + wm * 32 * WM + i * 32 + l31];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < WN; ++j) b[j] = Bc[(2 * s + lh) * TN + wn * 32 * WN + j * 32 + l31];
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
             if (s == 3) {
                 if (NBUF == 2) {
@@ -889,14 +903,14 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
 
     float* out = p.part + (size_t)split * p.k * p.ncols;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < WN; ++j) {
+        const int col = n0 + wn * 32 * WN + j * 32 + l31;
         if (col >= p.ncols) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < WM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < p.k) out[(size_t)row * p.ncols + col] = acc[i][j][r];
             }
         }
@@ -1024,10 +1038,19 @@ extern "C" int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, co
     return launch_igemm_nt(p, vspw_stream(stream));
 }
 
+// tile of the weight-gradient GEMM: 64 wide on a side whose extent is <= 64 (only on the v2 path)
+static void wgrad_tile(const vspw_conv_desc* d, int& tm, int& tn) {
+    const bool vec = (d->k % 4 == 0) && (d->c % 4 == 0);
+    tm = (vec && d->k <= 64) ? 64 : BM;
+    tn = (vec && d->kh * d->kw * d->c <= 64) ? 64 : BN;
+}
+
 static void wgrad_plan(const vspw_conv_desc* d, int& splits, int& chunk) {
     long long P = (long long)d->n * d->oh * d->ow;
     int ncols = d->kh * d->kw * d->c;
-    long long tiles = (long long)vspw_cdiv(d->k, BM) * vspw_cdiv(ncols, BN);
+    int tm, tn;
+    wgrad_tile(d, tm, tn);
+    long long tiles = (long long)vspw_cdiv(d->k, tm) * vspw_cdiv(ncols, tn);
     long long want = (768 + tiles / 2) / tiles;  // 3 workgroups per CU, all resident at once (single LDS buffer)
     long long max_splits = (P + 255) / 256;
     if (want > max_splits) want = max_splits;
@@ -1068,15 +1091,27 @@ extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, 
     p.chunk = chunk;
     p.vec_a = (d->k % 4 == 0) ? 1 : 0;
     p.vec_b = (d->c % 4 == 0) ? 1 : 0;
-    int tiles = vspw_cdiv(p.k, BM) * vspw_cdiv(p.ncols, BN);
     const bool v2 = p.vec_a && p.vec_b && (long long)p.P * p.k < 0x7fffffffLL &&
                     (long long)d->n * d->h * d->w * d->c < 0x7fffffffLL;
-    if (v2 && p.ow >= BK)
-        hipLaunchKernelGGL((igemm_tn_v2_kernel<true, TN_NBUF>), dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
-    else if (v2)
-        hipLaunchKernelGGL((igemm_tn_v2_kernel<false, 2>), dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
-    else
-        hipLaunchKernelGGL(igemm_tn_kernel, dim3(tiles, splits), dim3(256), 0, vspw_stream(stream), p);
+    int tm, tn;
+    wgrad_tile(d, tm, tn);
+    if (!v2) tm = tn = 128;
+    const dim3 grid(vspw_cdiv(p.k, tm) * vspw_cdiv(p.ncols, tn), splits);
+    hipStream_t st_ = vspw_stream(stream);
+    if (!v2) {
+        hipLaunchKernelGGL(igemm_tn_kernel, grid, dim3(256), 0, st_, p);
+    } else if (p.ow < BK) {
+        hipLaunchKernelGGL((igemm_tn_v2_kernel<false, 2, 2, 2>), dim3(vspw_cdiv(p.k, 128) * vspw_cdiv(p.ncols, 128), splits),
+                           dim3(256), 0, st_, p);
+    } else if (tm == 128 && tn == 128) {
+        hipLaunchKernelGGL((igemm_tn_v2_kernel<true, TN_NBUF, 2, 2>), grid, dim3(256), 0, st_, p);
+    } else if (tm == 64 && tn == 128) {
+        hipLaunchKernelGGL((igemm_tn_v2_kernel<true, 1, 1, 2>), grid, dim3(256), 0, st_, p);
+    } else if (tm == 128 && tn == 64) {
+        hipLaunchKernelGGL((igemm_tn_v2_kernel<true, 1, 2, 1>), grid, dim3(256), 0, st_, p);
+    } else {
+        hipLaunchKernelGGL((igemm_tn_v2_kernel<true, 1, 1, 1>), grid, dim3(256), 0, st_, p);
+    }
     int st = vspw_launch_status();
     if (st != VSPW_OK) return st;
     if (splits > 1) {

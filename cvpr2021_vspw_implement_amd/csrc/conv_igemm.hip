@@ -427,6 +427,9 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
 #pragma unroll
             for (int j = 0; j < WN; ++j)
                 b[j] = *reinterpret_cast<const f32x4*>(&Bc[(wn * 32 * WN + j * 32 + l31) * LDA + kc * 8 + 4 * lh]);
+#ifdef VSPW_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -434,6 +437,9 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+#ifdef VSPW_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             if (kc == 0) {
                 if (NBUF == 2) {
                     // tile kt+1 has been in flight since the middle of the previous iteration: registers -> the

@@ -19,6 +19,7 @@
 // are in flight during the MFMA phase). fp32 MFMA issues one instruction per 64 cycles per SIMD,
 // so LDS and global bandwidth are far from binding; the kernel is MFMA-issue bound.
 #include "common.h"
+#include <cstdlib>
 
 #define BM 128
 #define BN 128
@@ -274,15 +275,18 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// v2 of the NT kernel for the vector path (C % 4 == 0, 32-bit offsets, forward or stride-1 data gradient):
-//   * two LDS buffers, ONE barrier per K-tile (tile k+1 is written to the other buffer while tile k is consumed);
-//   * the global loads of tile k+2 are issued piecewise between the four MFMA chunks of tile k and the whole loop body
-//     is straight-line (clamped always-valid addresses + select instead of branches), so the address arithmetic,
-//     ds_writes and ds_reads issue in the shadow of the 64-cycle fp32 MFMAs instead of in front of them;
-//   * (tap, channel) of a thread's k-column advance incrementally: no integer division in the loop.
+// v2 of the NT kernel for Cin % 32 == 0 (every conv of the path except the 3-channel stem conv), forward or stride-1
+// data gradient.  A K-tile (BK = 32 channels) never straddles a filter tap, so the tap (ky, kx) and the channel base
+// are WORKGROUP-UNIFORM: they live in scalar registers, and each thread caches, per tap, the byte offset of the
+// (clamped) source pixel of each of its rows plus an in-image bit.  The K loop then contains no per-load address
+// arithmetic at all - a load is `scalar base + cached 32-bit offset` - and the loop body is straight-line apart from
+// the uniform (scalar-branch) "tap changed" refresh every Cin/32 iterations.  Measured on the GEMM probe
+// (tools/probe/mfma_ablate.hip): VALU work in the loop is not hidden behind the fp32 MFMAs, it is added to them.
+//   * NBUF 2: two LDS buffers, ONE barrier per K-tile; NBUF 1: one buffer, two barriers, half the LDS (residency).
+//   * zeroing of out-of-image taps is a select applied when the registers are written to LDS (one K-tile later), so
+//     no vmcnt wait is forced near the load; rows >= M and columns >= Cout read clamped (valid) addresses and are
+//     simply never stored.
 // MODE 0: forward gather (any stride);  MODE 1: data-gradient gather, stride 1.
-// NBUF 2: as described.  NBUF 1: one LDS buffer and two barriers per K-tile (half the LDS, so the 64-row tiles keep
-// 4 workgroups per CU resident) but the same straight-line, MFMA-shadowed load path.
 // WGM = waves along M (2: 2x2 waves, 1: 1x4 waves); workgroup tile = (32*WM*WGM) x (32*WN*(4/WGM)).
 template <int WGM, int WM, int WN, int MODE, int NBUF>
 __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
@@ -307,88 +311,96 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
     const int lrow = tid >> 3;
     const int lcol = (tid & 7) * 4;
 
-    int a_base[RA], a_by[RA], a_bx[RA];
-    bool a_ok[RA];
+    // offsets are relative to the first image this tile touches (uniform 64-bit base), so 32-bit byte offsets suffice
     const int ohw = p.oh * p.ow;
+    const int img0 = m0 / ohw;
+    const char* src0 = reinterpret_cast<const char*>(p.src + (size_t)img0 * p.h * p.w * p.c);
+    const char* wt0 = reinterpret_cast<const char*>(p.wt + (size_t)n0 * p.kdim);
+    const bool pointwise = (p.kh * p.kw == 1) & (p.stride == 1) & (p.pad == 0);  // uniform: src pixel == output pixel
+
+    int a_base[RA], a_by[RA], a_bx[RA];
+    unsigned a_voff[RA];    // byte offset (from src0) of this row's source pixel for the current tap, + lcol
+    unsigned a_okbits = 0;  // bit i: that pixel is inside the image
+    if (pointwise) {
 #pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        const int m = m0 + lrow + 32 * i;
-        a_ok[i] = m < p.m;
-        const int mm = a_ok[i] ? m : 0;
-        const int n = mm / ohw;
-        const int r = mm - n * ohw;
-        const int oy = r / p.ow;
-        const int ox = r - oy * p.ow;
-        a_base[i] = n * p.h;
-        if (MODE == 0) {
-            a_by[i] = oy * p.stride - p.pad;
-            a_bx[i] = ox * p.stride - p.pad;
-        } else {
-            a_by[i] = oy + p.pad;
-            a_bx[i] = ox + p.pad;
+        for (int i = 0; i < RA; ++i) {
+            const int m = min(m0 + lrow + 32 * i, p.m - 1) - img0 * ohw;
+            a_voff[i] = (unsigned)(m * p.c + lcol) * 4u;
+            a_base[i] = a_by[i] = a_bx[i] = 0;
+        }
+        a_okbits = (1u << RA) - 1u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int mm = min(m0 + lrow + 32 * i, p.m - 1);
+            const int n = mm / ohw;
+            const int r = mm - n * ohw;
+            const int oy = r / p.ow;
+            const int ox = r - oy * p.ow;
+            a_base[i] = (n - img0) * p.h;
+            if (MODE == 0) {
+                a_by[i] = oy * p.stride - p.pad;
+                a_bx[i] = ox * p.stride - p.pad;
+            } else {
+                a_by[i] = oy + p.pad;
+                a_bx[i] = ox + p.pad;
+            }
         }
     }
-    bool b_ok[RB];
-    int b_off[RB];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) {
-        const int n = n0 + lrow + 32 * i;
-        b_ok[i] = n < p.nout;
-        b_off[i] = (b_ok[i] ? n : 0) * p.kdim;
-    }
-
-    // this thread's k-column state: k4 = kt*32 + lcol -> (ky, kx, ci)
-    int k4 = lcol;
-    int ci, ky, kx;
-    {
-        const int tap = k4 / p.c;
-        ci = k4 - tap * p.c;
-        ky = tap / p.kw;
-        kx = tap - ky * p.kw;
-    }
-    // c >= BK on this path (host check), so a +32 step crosses at most one tap boundary: branch-free update
-    auto advance = [&]() {
-        k4 += BK;
-        ci += BK;
-        const bool wrap = ci >= p.c;
-        ci = wrap ? ci - p.c : ci;
-        kx = wrap ? kx + 1 : kx;
-        const bool wrapx = kx == p.kw;
-        kx = wrapx ? 0 : kx;
-        ky = wrapx ? ky + 1 : ky;
-    };
     const int sgn = (MODE == 0) ? p.dil : -p.dil;
-    // Loads always use a clamped, valid address; the zeroing of out-of-image / past-K taps is a select applied when
-    // the registers are written to LDS (one K-tile later), so no vmcnt wait is forced near the load.
-    f32x4 ra[RA], rb[RB];
-    bool oka[RA], okb[RB];
-    auto load_a = [&](int i) {
-        const bool kin = k4 < p.kdim;
-        const int sy = a_by[i] + sgn * ky;
-        const int sx = a_bx[i] + sgn * kx;
-        oka[i] = kin & a_ok[i] & ((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w);
-        const int syc = min(max(sy, 0), p.h - 1), sxc = min(max(sx, 0), p.w - 1);
-        const int off = ((a_base[i] + syc) * p.w + sxc) * p.c + (kin ? ci : 0);
-        ra[i] = *reinterpret_cast<const f32x4*>(p.src + off);
+    auto set_tap = [&](int ky, int kx) {
+        a_okbits = 0;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int sy = a_by[i] + sgn * ky;
+            const int sx = a_bx[i] + sgn * kx;
+            const bool ok = ((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w);
+            const int syc = min(max(sy, 0), p.h - 1), sxc = min(max(sx, 0), p.w - 1);
+            a_voff[i] = (unsigned)(((a_base[i] + syc) * p.w + sxc) * p.c + lcol) * 4u;
+            a_okbits |= ok ? (1u << i) : 0u;
+        }
     };
-    auto load_b = [&](int i) {
-        okb[i] = (k4 < p.kdim) & b_ok[i];
-        rb[i] = *reinterpret_cast<const f32x4*>(p.wt + (okb[i] ? b_off[i] + k4 : 0));
+    if (!pointwise) set_tap(0, 0);
+    unsigned b_voff[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) b_voff[i] = (unsigned)(min(lrow + 32 * i, p.nout - 1 - n0) * p.kdim + lcol) * 4u;
+
+    // uniform K state: kb = k offset of the tile the next load fetches, cb = its channel base inside tap (ky, kx)
+    int kb = 0, cb = 0, ky = 0, kx = 0;
+    bool more = true;
+    auto advance = [&]() {
+        kb += BK;
+        cb += BK;
+        more = kb < p.kdim;
+        if (more && cb == p.c) {
+            cb = 0;
+            if (++kx == p.kw) {
+                kx = 0;
+                ++ky;
+            }
+            set_tap(ky, kx);
+        }
+    };
+    f32x4 ra[RA], rb[RB];
+    unsigned ok_regs = 0;  // in-image bits of the tile currently held in ra[]
+    auto load_tile = [&]() {
+        if (more) {
+            const char* sa = src0 + (size_t)cb * 4;
+            const char* sb = wt0 + (size_t)kb * 4;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(sa + a_voff[i]);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(sb + b_voff[i]);
+            ok_regs = a_okbits;
+        }
     };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto store_tile = [&](float* Ad, float* Bd) {
 #pragma unroll
         for (int i = 0; i < RA; ++i)
-            *reinterpret_cast<f32x4*>(&Ad[(lrow + 32 * i) * LDA + lcol]) = oka[i] ? ra[i] : zero4;
+            *reinterpret_cast<f32x4*>(&Ad[(lrow + 32 * i) * LDA + lcol]) = ((ok_regs >> i) & 1u) ? ra[i] : zero4;
 #pragma unroll
-        for (int i = 0; i < RB; ++i)
-            *reinterpret_cast<f32x4*>(&Bd[(lrow + 32 * i) * LDA + lcol]) = okb[i] ? rb[i] : zero4;
-    };
-    auto load_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < RA; ++i) load_a(i);
-#pragma unroll
-        for (int i = 0; i < RB; ++i) load_b(i);
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bd[(lrow + 32 * i) * LDA + lcol]) = rb[i];
     };
 
     f32x16 acc[WM][WN];
@@ -399,12 +411,12 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = (p.kdim + BK - 1) / BK;
+    const int nk = p.kdim / BK;
     // prologue: tile 0 -> LDS[0]; tile 1 -> registers
     load_tile();
     if (NBUF == 2) {
         store_tile(As[0], Bs[0]);
-        advance();  // state now describes tile 1 (loads past kdim are zeroed at store time)
+        advance();  // state now describes tile 1 (tiles past kdim are not fetched; stale registers are never consumed)
         load_tile();
         __syncthreads();
     }
@@ -538,7 +550,8 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
         int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
         // measured: short reductions (K <= 1024, i.e. the 1x1 convs) gain ~10 % from the higher residency of the
         // single-buffer variant (3 workgroups/CU); long ones gain 2-5 % from the second buffer (one barrier per tile)
-        if (p.kdim <= 1024)
+        static const int nbuf1_max_k = getenv("VSPW_NBUF1_MAXK") ? atoi(getenv("VSPW_NBUF1_MAXK")) : 1024;
+        if (p.kdim <= nbuf1_max_k)
             hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
         else
             hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 2>), dim3(tiles), dim3(256), 0, st, p);
@@ -560,9 +573,10 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
 // buffers, the smaller tiles one (two would cap residency at 2 workgroups/CU and lose)
 static int nt_decide(const IgemmNT& p, bool& v2) {
     int cfg = nt_pick_tile(p.m, p.nout);
-    const long long src_elems = (long long)p.nb * p.h * p.w * p.c;
-    const long long wt_elems = (long long)p.nout * p.kdim;
-    v2 = cfg != 21 && p.vec && p.c >= BK && src_elems < 0x7fffffffLL && wt_elems < 0x7fffffffLL &&
+    // 32-bit byte offsets relative to the first image a tile touches / the tile's first weight row
+    const long long img_elems = (long long)p.h * p.w * p.c;
+    const long long span = (128 / ((long long)p.oh * p.ow) + 2) * img_elems;
+    v2 = cfg != 21 && p.vec && p.c % BK == 0 && span < (1LL << 30) && (long long)p.kdim < (1LL << 22) &&
          (p.mode == 0 || p.stride == 1);
     if (!v2 && cfg == 31) cfg = 12;  // the generic kernel has no 96-row instantiation
     return cfg;

@@ -758,17 +758,27 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(IgemmTN p) {
 }
 
 // v2 of the TN kernel for the vector path (Cout % 4 == 0, Cin % 4 == 0, 32-bit offsets): same pipeline as
-// igemm_nt_v2_kernel — two LDS buffers, one barrier per 32-pixel K-tile, straight-line loop body with clamped
-// always-valid addresses (zeroing applied when the registers are written to LDS), next-next tile's global loads issued
-// in the shadow of the MFMAs.
+// igemm_nt_v2_kernel - straight-line loop body, always-valid addresses (zeroing applied when the registers are written
+// to LDS), the next tile's global loads issued in the shadow of the MFMAs.
+// Gather mode G (how the 32 pixels of a K-tile are turned into addresses of x):
+//   0  generic, two integer divisions per staged row per K-tile (narrow feature maps, ow < 32)
+//   1  generic, incremental (image, y, x) update (ow >= 32)
+//   2  linear: stride 1 and same-size output (oh == h, ow == w: every 3x3 conv of layers 1-4 but the three strided
+//      ones), so the source pixel of (output pixel pp, tap) is pp + tap offset - the per-tile part of every address
+//      is a workgroup-uniform base bump (scalar registers) and the per-thread part a constant 32-bit offset; only the
+//      in-image test of the tap still needs the (y, x) of the row, updated incrementally (ow >= 32)
+//   3  pointwise (1x1, stride 1, no padding): linear and always in-image, no pixel coordinates at all
+// VALU work in this loop is not hidden behind the fp32 MFMAs (tools/probe/mfma_ablate.hip), hence the modes.
 #ifndef TN_NBUF
 #define TN_NBUF 1
 #endif
 // WM / WN = MFMA 32x32 blocks per wave along Cout / along (tap, Cin); 2x2 waves -> tile (64*WM) x (64*WN).
 // Narrow weight matrices (Cout <= 64 or KH*KW*Cin <= 64: the stem, layer1, 1x1 convs to/from 64 channels) use
 // WM = 1 / WN = 1 so that no half of the MFMA tile is spent on padding.
-template <bool WIDE, int NBUF, int WM, int WN>
+template <int G, int NBUF, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
+    constexpr bool LIN = G >= 2;
+    constexpr bool WIDE = G >= 1;
     constexpr int TM = 64 * WM, TN = 64 * WN;
     constexpr int A4 = TM / 4, B4 = TN / 4;          // float4 per staged row
     constexpr int RPA = 256 / A4, RPB = 256 / B4;    // rows covered per pass
@@ -793,10 +803,11 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     const int krow_a = tid / A4, ca4 = (tid % A4) * 4;
     const int krow_b = tid / B4, cb4 = (tid % B4) * 4;
 
-    // this thread's A column (co) and B column (tap, ci): fixed for the whole kernel
-    const int co = m0 + ca4;
+    // this thread's A column (co) and B column (tap, ci): fixed for the whole kernel.  The linear modes clamp them to
+    // the last valid float4 instead of masking: rows / columns of dW past the matrix are computed and never stored.
+    const int co = LIN ? min(m0 + ca4, p.k - 4) : m0 + ca4;
     const bool a_colok = co < p.k;
-    const int ncol = n0 + cb4;
+    const int ncol = LIN ? min(n0 + cb4, p.ncols - 4) : n0 + cb4;
     const bool b_colok = ncol < p.ncols;
     int b_ci, b_dy, b_dx;
     {
@@ -815,16 +826,38 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     // the linear pixel index.
     int pk0 = p_begin;
     int r_n[PB], r_oy[PB], r_ox[PB];
+    if (G != 3) {
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-        const int pp = p_begin + krow_b + RPB * i;
-        r_n[i] = pp / ohw;
-        const int r = pp - r_n[i] * ohw;
-        r_oy[i] = r / p.ow;
-        r_ox[i] = r - r_oy[i] * p.ow;
+        for (int i = 0; i < PB; ++i) {
+            const int pp = p_begin + krow_b + RPB * i;
+            r_n[i] = pp / ohw;
+            const int r = pp - r_n[i] * ohw;
+            r_oy[i] = r / p.ow;
+            r_ox[i] = r - r_oy[i] * p.ow;
+        }
+    }
+    // linear modes: uniform bases (bumped per K-tile) + constant per-thread byte offsets.  xb points (pad rows + pad
+    // pixels) before the tile's first pixel so that every tap offset is non-negative; it is only dereferenced with
+    // offsets that land inside the tensor.
+    const char* dyb = reinterpret_cast<const char*>(p.dy) + (size_t)p_begin * p.k * 4;
+    const char* xb = reinterpret_cast<const char*>(p.x) + ((long long)p_begin - p.pad * p.w - p.pad) * p.c * 4;
+    unsigned a_voff[PA], b_voff[PB];
+    const unsigned a_safe = (unsigned)co * 4u;                                      // row 0 of the tile, same column
+    const unsigned b_safe = (unsigned)((p.pad * p.w + p.pad) * p.c + b_ci) * 4u;    // centre tap of row 0
+    if (LIN) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) a_voff[i] = (unsigned)((krow_a + RPA * i) * p.k + co) * 4u;
+        const int tapoff = ((b_dy + p.pad) * p.w + (b_dx + p.pad)) * p.c + b_ci;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) b_voff[i] = (unsigned)((krow_b + RPB * i) * p.c + tapoff) * 4u;
     }
     auto advance = [&]() {
         pk0 += BK;
+        if (LIN) {
+            dyb += (size_t)BK * p.k * 4;
+            xb += (size_t)BK * p.c * 4;
+        }
+        if (G == 3) return;
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             if (WIDE) {  // ow >= BK: at most one row wrap per step
@@ -834,7 +867,7 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
                 r_oy[i] = wx ? r_oy[i] + 1 : r_oy[i];
                 const bool wy = r_oy[i] >= p.oh;
                 r_oy[i] = wy ? 0 : r_oy[i];
-                r_n[i] = wy ? r_n[i] + 1 : r_n[i];
+                if (!LIN) r_n[i] = wy ? r_n[i] + 1 : r_n[i];
             } else {
                 const int pp = pk0 + krow_b + RPB * i;
                 r_n[i] = pp / ohw;
@@ -847,6 +880,25 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     f32x4 ra[PA], rb[PB];
     bool oka[PA], okb[PB];
     auto load_tile = [&]() {
+        if (LIN) {
+            const int rows_left = p_end - pk0;  // uniform
+            if (rows_left <= 0) return;         // prefetch past the chunk: nothing to fetch, registers never consumed
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                oka[i] = (krow_a + RPA * i) < rows_left;
+                ra[i] = *reinterpret_cast<const f32x4*>(dyb + (oka[i] ? a_voff[i] : a_safe));
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                okb[i] = (krow_b + RPB * i) < rows_left;
+                if (G == 2) {
+                    const int sy = r_oy[i] + b_dy, sx = r_ox[i] + b_dx;
+                    okb[i] = okb[i] & ((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w);
+                }
+                rb[i] = *reinterpret_cast<const f32x4*>(xb + (okb[i] ? b_voff[i] : b_safe));
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int pp = pk0 + krow_a + RPA * i;
@@ -1120,17 +1172,24 @@ extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, 
     hipStream_t st_ = vspw_stream(stream);
     if (!v2) {
         hipLaunchKernelGGL(igemm_tn_kernel, grid, dim3(256), 0, st_, p);
-    } else if (p.ow < BK) {
-        hipLaunchKernelGGL((igemm_tn_v2_kernel<false, 2, 2, 2>), dim3(vspw_cdiv(p.k, 128) * vspw_cdiv(p.ncols, 128), splits),
-                           dim3(256), 0, st_, p);
-    } else if (tm == 128 && tn == 128) {
-        hipLaunchKernelGGL((igemm_tn_v2_kernel<true, TN_NBUF, 2, 2>), grid, dim3(256), 0, st_, p);
-    } else if (tm == 64 && tn == 128) {
-        hipLaunchKernelGGL((igemm_tn_v2_kernel<true, 1, 1, 2>), grid, dim3(256), 0, st_, p);
-    } else if (tm == 128 && tn == 64) {
-        hipLaunchKernelGGL((igemm_tn_v2_kernel<true, 1, 2, 1>), grid, dim3(256), 0, st_, p);
     } else {
-        hipLaunchKernelGGL((igemm_tn_v2_kernel<true, 1, 1, 1>), grid, dim3(256), 0, st_, p);
+        // gather mode (see igemm_tn_v2_kernel)
+        const bool same = d->stride == 1 && d->oh == d->h && d->ow == d->w;
+        const bool point = same && d->kh * d->kw == 1 && d->pad == 0;
+        const int g = point ? 3 : (same && p.ow >= BK) ? 2 : (p.ow >= BK ? 1 : 0);
+        const int code = g * 100 + (tm / 64) * 10 + (tn / 64);
+#define TN_CASE(G, NB, WM_, WN_) \
+    case G * 100 + WM_ * 10 + WN_: \
+        hipLaunchKernelGGL((igemm_tn_v2_kernel<G, NB, WM_, WN_>), grid, dim3(256), 0, st_, p); \
+        break;
+        switch (code) {
+            TN_CASE(0, 2, 2, 2) TN_CASE(0, 1, 1, 2) TN_CASE(0, 1, 2, 1) TN_CASE(0, 1, 1, 1)
+            TN_CASE(1, TN_NBUF, 2, 2) TN_CASE(1, 1, 1, 2) TN_CASE(1, 1, 2, 1) TN_CASE(1, 1, 1, 1)
+            TN_CASE(2, TN_NBUF, 2, 2) TN_CASE(2, 1, 1, 2) TN_CASE(2, 1, 2, 1) TN_CASE(2, 1, 1, 1)
+            TN_CASE(3, TN_NBUF, 2, 2) TN_CASE(3, 1, 1, 2) TN_CASE(3, 1, 2, 1) TN_CASE(3, 1, 1, 1)
+            default: return VSPW_EINVAL;
+        }
+#undef TN_CASE
     }
     int st = vspw_launch_status();
     if (st != VSPW_OK) return st;

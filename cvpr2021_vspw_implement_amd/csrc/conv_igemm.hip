@@ -467,23 +467,46 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
     }
 
     float csum[WN], csq[WN];
+    if ((m0 + TM <= p.m) & (n0 + TN <= p.nout)) {
+        // interior tile (uniform test): unguarded stores at `uniform base + constant per-lane byte offset`
+        char* dbase = reinterpret_cast<char*>(p.dst + (size_t)m0 * p.ldd + n0);
+        const unsigned lane_off = (unsigned)((wm * 32 * WM + 4 * lh) * p.ldd + wn * 32 * WN + l31) * 4u;
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        csum[j] = 0.f;
-        csq[j] = 0.f;
-        const int col = n0 + wn * 32 * WN + j * 32 + l31;
-        const bool cok = col < p.nout;
-        const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+        for (int j = 0; j < WN; ++j) {
+            csum[j] = 0.f;
+            csq[j] = 0.f;
+            const float bv = (p.bias != nullptr) ? p.bias[n0 + wn * 32 * WN + j * 32 + l31] : 0.f;
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
+            for (int i = 0; i < WM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (cok && row < p.m) {
-                    float v = acc[i][j][r] + bv;
-                    p.dst[(size_t)row * p.ldd + col] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const size_t uoff = ((size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldd + j * 32) * 4;  // uniform
+                    const float v = acc[i][j][r] + bv;
+                    *reinterpret_cast<float*>(dbase + uoff + lane_off) = v;
                     csum[j] += v;
                     csq[j] += v * v;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            csum[j] = 0.f;
+            csq[j] = 0.f;
+            const int col = n0 + wn * 32 * WN + j * 32 + l31;
+            const bool cok = col < p.nout;
+            const float bv = (p.bias != nullptr && cok) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (cok && row < p.m) {
+                        float v = acc[i][j][r] + bv;
+                        p.dst[(size_t)row * p.ldd + col] = v;
+                        csum[j] += v;
+                        csq[j] += v * v;
+                    }
                 }
             }
         }

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvspw_hip.so")
 class ConvDesc(ctypes.Structure):
     """struct vspw_conv_desc (include/vspw_hip.h)."""
 
-    _fields_ = [(n, ctypes.c_int) for n in ("n", "h", "w", "c", "oh", "ow", "k", "kh", "kw", "stride", "pad", "dil")]
+    _fields_ = [(n, ctypes.c_int) for n in ("n", "h", "w", "c", "oh", "ow", "k", "kh", "kw", "stride", "pad", "dil", "pad_w")]
 
 
 _CTYPES = {

@@ -34,12 +34,21 @@ struct IgemmNT {
     float* stat_part;   // optional [tiles_m][2][nout] per-tile column sum / sumsq (fused BN stats)
     int nb, h, w, c;    // src dims
     int oh, ow;         // pixel grid of the GEMM M dimension
-    int kh, kw, stride, pad, dil;
+    int kh, kw, stride, pad, padw, dil;  // pad: rows (H), padw: columns (W)
     int mode;           // 0: forward gather, 1: data-gradient gather
     int nout, ldd;
     int m, kdim;
-    int vec;            // 1: float4 loads are legal (c % 4 == 0)
+    int vec;            // 1: float4 loads are legal (c % 4 == 0 and lds % 4 == 0)
+    int lds;            // pixel stride of src in floats (c, or wider when src is a channel slice of a concat buffer)
+    int act;            // epilogue activation: 0 none, 1 relu, 2 sigmoid, 3 tanh (inference-only entry point)
 };
+
+__device__ __forceinline__ float nt_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return 1.f / (1.f + expf(-v));
+    if (act == 3) return tanhf(v);
+    return v;
+}
 
 __device__ __forceinline__ bool nt_src_coord(const IgemmNT& p, int by, int bx, int ky, int kx, int& sy, int& sx) {
     if (p.mode == 0) {
@@ -110,10 +119,10 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
         a_img[i] = n;
         if (p.mode == 0) {
             a_by[i] = oy * p.stride - p.pad;
-            a_bx[i] = ox * p.stride - p.pad;
+            a_bx[i] = ox * p.stride - p.padw;
         } else {
             a_by[i] = oy + p.pad;
-            a_bx[i] = ox + p.pad;
+            a_bx[i] = ox + p.padw;
         }
     }
     bool b_ok[RB];
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 int sy, sx;
                 if (kin && a_ok[i] && nt_src_coord(p, a_by[i], a_bx[i], ky, kx, sy, sx)) {
-                    size_t off = (((size_t)a_img[i] * p.h + sy) * p.w + sx) * (size_t)p.c + ci;
+                    size_t off = (((size_t)a_img[i] * p.h + sy) * p.w + sx) * (size_t)p.lds + ci;
                     v = *reinterpret_cast<const f32x4*>(p.src + off);
                 }
                 ra[i] = v;
@@ -168,7 +177,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
                         int kx = tap - ky * p.kw;
                         int sy, sx;
                         if (a_ok[i] && nt_src_coord(p, a_by[i], a_bx[i], ky, kx, sy, sx)) {
-                            size_t off = (((size_t)a_img[i] * p.h + sy) * p.w + sx) * (size_t)p.c + ci;
+                            size_t off = (((size_t)a_img[i] * p.h + sy) * p.w + sx) * (size_t)p.lds + ci;
                             v[e] = p.src[off];
                         }
                     }
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (cok && row < p.m) {
-                    float v = acc[i][j][r] + bv;
+                    float v = nt_act(acc[i][j][r] + bv, p.act);
                     p.dst[(size_t)row * p.ldd + col] = v;
                     csum[j] += v;
                     csq[j] += v * v;
@@ -314,9 +323,9 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
     // offsets are relative to the first image this tile touches (uniform 64-bit base), so 32-bit byte offsets suffice
     const int ohw = p.oh * p.ow;
     const int img0 = m0 / ohw;
-    const char* src0 = reinterpret_cast<const char*>(p.src + (size_t)img0 * p.h * p.w * p.c);
+    const char* src0 = reinterpret_cast<const char*>(p.src + (size_t)img0 * p.h * p.w * p.lds);
     const char* wt0 = reinterpret_cast<const char*>(p.wt + (size_t)n0 * p.kdim);
-    const bool pointwise = (p.kh * p.kw == 1) & (p.stride == 1) & (p.pad == 0);  // uniform: src pixel == output pixel
+    const bool pointwise = (p.kh * p.kw == 1) & (p.stride == 1) & (p.pad == 0) & (p.padw == 0);  // src pixel == out pixel
 
     int a_base[RA], a_by[RA], a_bx[RA];
     unsigned a_voff[RA];    // byte offset (from src0) of this row's source pixel for the current tap, + lcol
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int m = min(m0 + lrow + 32 * i, p.m - 1) - img0 * ohw;
-            a_voff[i] = (unsigned)(m * p.c + lcol) * 4u;
+            a_voff[i] = (unsigned)(m * p.lds + lcol) * 4u;
             a_base[i] = a_by[i] = a_bx[i] = 0;
         }
         a_okbits = (1u << RA) - 1u;
@@ -340,10 +349,10 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
             a_base[i] = (n - img0) * p.h;
             if (MODE == 0) {
                 a_by[i] = oy * p.stride - p.pad;
-                a_bx[i] = ox * p.stride - p.pad;
+                a_bx[i] = ox * p.stride - p.padw;
             } else {
                 a_by[i] = oy + p.pad;
-                a_bx[i] = ox + p.pad;
+                a_bx[i] = ox + p.padw;
             }
         }
     }
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
             const int sx = a_bx[i] + sgn * kx;
             const bool ok = ((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w);
             const int syc = min(max(sy, 0), p.h - 1), sxc = min(max(sx, 0), p.w - 1);
-            a_voff[i] = (unsigned)(((a_base[i] + syc) * p.w + sxc) * p.c + lcol) * 4u;
+            a_voff[i] = (unsigned)(((a_base[i] + syc) * p.w + sxc) * p.lds + lcol) * 4u;
             a_okbits |= ok ? (1u << i) : 0u;
         }
     };
@@ -467,7 +476,7 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
     }
 
     float csum[WN], csq[WN];
-    if ((m0 + TM <= p.m) & (n0 + TN <= p.nout)) {
+    if ((m0 + TM <= p.m) & (n0 + TN <= p.nout) & (p.act == 0)) {
         // interior tile (uniform test): unguarded stores at `uniform base + constant per-lane byte offset`
         char* dbase = reinterpret_cast<char*>(p.dst + (size_t)m0 * p.ldd + n0);
         const unsigned lane_off = (unsigned)((wm * 32 * WM + 4 * lh) * p.ldd + wn * 32 * WN + l31) * 4u;
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (cok && row < p.m) {
-                        float v = acc[i][j][r] + bv;
+                        float v = nt_act(acc[i][j][r] + bv, p.act);
                         p.dst[(size_t)row * p.ldd + col] = v;
                         csum[j] += v;
                         csq[j] += v * v;
@@ -597,7 +606,7 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
 static int nt_decide(const IgemmNT& p, bool& v2) {
     int cfg = nt_pick_tile(p.m, p.nout);
     // 32-bit byte offsets relative to the first image a tile touches / the tile's first weight row
-    const long long img_elems = (long long)p.h * p.w * p.c;
+    const long long img_elems = (long long)p.h * p.w * p.lds;
     const long long span = (128 / ((long long)p.oh * p.ow) + 2) * img_elems;
     v2 = cfg != 21 && p.vec && p.c % BK == 0 && span < (1LL << 30) && (long long)p.kdim < (1LL << 22) &&
          (p.mode == 0 || p.stride == 1);
@@ -640,7 +649,7 @@ struct IgemmTN {
     float* part;      // [splits][k][ncols]
     int nb, h, w, c;
     int oh, ow;
-    int kh, kw, stride, pad, dil;
+    int kh, kw, stride, pad, padw, dil;
     int k;       // Cout (GEMM M)
     int ncols;   // kh*kw*c (GEMM N)
     int P;       // nb*oh*ow (GEMM K)
@@ -705,7 +714,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(IgemmTN p) {
                 const int r = pp - n * ohw;
                 const int oy = r / p.ow;
                 const int ox = r - oy * p.ow;
-                const int by = oy * p.stride - p.pad, bx = ox * p.stride - p.pad;
+                const int by = oy * p.stride - p.pad, bx = ox * p.stride - p.padw;
                 if (p.vec_b) {
                     if (b_colok[0]) {
                         int sy = by + b_ky[0] * p.dil, sx = bx + b_kx[0] * p.dil;
@@ -840,7 +849,7 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
         const int ky = tap / p.kw;
         const int kx = tap - ky * p.kw;
         b_dy = ky * p.dil - p.pad;
-        b_dx = kx * p.dil - p.pad;
+        b_dx = kx * p.dil - p.padw;
     }
     const int ohw = p.oh * p.ow;
 
@@ -863,14 +872,14 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     // pixels) before the tile's first pixel so that every tap offset is non-negative; it is only dereferenced with
     // offsets that land inside the tensor.
     const char* dyb = reinterpret_cast<const char*>(p.dy) + (size_t)p_begin * p.k * 4;
-    const char* xb = reinterpret_cast<const char*>(p.x) + ((long long)p_begin - p.pad * p.w - p.pad) * p.c * 4;
+    const char* xb = reinterpret_cast<const char*>(p.x) + ((long long)p_begin - p.pad * p.w - p.padw) * p.c * 4;
     unsigned a_voff[PA], b_voff[PB];
     const unsigned a_safe = (unsigned)co * 4u;                                      // row 0 of the tile, same column
-    const unsigned b_safe = (unsigned)((p.pad * p.w + p.pad) * p.c + b_ci) * 4u;    // centre tap of row 0
+    const unsigned b_safe = (unsigned)((p.pad * p.w + p.padw) * p.c + b_ci) * 4u;    // centre tap of row 0
     if (LIN) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) a_voff[i] = (unsigned)((krow_a + RPA * i) * p.k + co) * 4u;
-        const int tapoff = ((b_dy + p.pad) * p.w + (b_dx + p.pad)) * p.c + b_ci;
+        const int tapoff = ((b_dy + p.pad) * p.w + (b_dx + p.padw)) * p.c + b_ci;
 #pragma unroll
         for (int i = 0; i < PB; ++i) b_voff[i] = (unsigned)((krow_b + RPB * i) * p.c + tapoff) * 4u;
     }
@@ -1076,9 +1085,9 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restr
 static int conv_geometry_ok(const vspw_conv_desc* d) {
     if (!d) return 0;
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0 || d->k <= 0) return 0;
-    if (d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0) return 0;
+    if (d->kh <= 0 || d->kw <= 0 || d->stride <= 0 || d->dil <= 0 || d->pad < 0 || d->pad_w < 0) return 0;
     int oh = (d->h + 2 * d->pad - d->dil * (d->kh - 1) - 1) / d->stride + 1;
-    int ow = (d->w + 2 * d->pad - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+    int ow = (d->w + 2 * d->pad_w - d->dil * (d->kw - 1) - 1) / d->stride + 1;
     return oh == d->oh && ow == d->ow && oh > 0 && ow > 0;
 }
 
@@ -1086,7 +1095,7 @@ static bool fill_fwd_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr;
     p.nb = d->n; p.h = d->h; p.w = d->w; p.c = d->c;
     p.oh = d->oh; p.ow = d->ow;
-    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;
     p.mode = 0;
     p.nout = d->k; p.ldd = d->k;
     long long m = (long long)d->n * d->oh * d->ow;
@@ -1094,6 +1103,8 @@ static bool fill_fwd_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.m = (int)m;
     p.kdim = d->kh * d->kw * d->c;
     p.vec = (d->c % 4 == 0) ? 1 : 0;
+    p.lds = d->c;
+    p.act = 0;
     return true;
 }
 
@@ -1115,6 +1126,20 @@ extern "C" int vspw_conv2d_fwd(const vspw_conv_desc* d, const float* x, const fl
     return launch_igemm_nt(p, vspw_stream(stream));
 }
 
+extern "C" int vspw_conv2d_fwd_ex(const vspw_conv_desc* d, const float* x, long long ldx, const float* w,
+                                  const float* bias, int act, float* y, long long ldy, void* stream) {
+    if (!conv_geometry_ok(d) || !x || !w || !y || ldx < d->c || ldy < d->k || act < 0 || act > 3) return VSPW_EINVAL;
+    if (ldx > 0x7fffffffLL || ldy > 0x7fffffffLL) return VSPW_EINVAL;
+    IgemmNT p;
+    if (!fill_fwd_params(d, p)) return VSPW_EINVAL;
+    p.src = x; p.wt = w; p.bias = bias; p.dst = y; p.stat_part = nullptr;
+    p.lds = (int)ldx;
+    p.ldd = (int)ldy;
+    p.act = act;
+    p.vec = (d->c % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0) ? 1 : 0;
+    return launch_igemm_nt(p, vspw_stream(stream));
+}
+
 extern "C" int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, const float* wT, float* dx,
                                     void* stream) {
     if (!conv_geometry_ok(d) || !dy || !wT || !dx) return VSPW_EINVAL;
@@ -1122,7 +1147,7 @@ extern "C" int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, co
     p.src = dy; p.wt = wT; p.bias = nullptr; p.dst = dx; p.stat_part = nullptr;
     p.nb = d->n; p.h = d->oh; p.w = d->ow; p.c = d->k;   // gather over dY
     p.oh = d->h; p.ow = d->w;                              // rows are input pixels
-    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;
     p.mode = 1;
     p.nout = d->c; p.ldd = d->c;
     long long m = (long long)d->n * d->h * d->w;
@@ -1130,6 +1155,8 @@ extern "C" int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, co
     p.m = (int)m;
     p.kdim = d->kh * d->kw * d->k;
     p.vec = (d->k % 4 == 0) ? 1 : 0;
+    p.lds = d->k;
+    p.act = 0;
     return launch_igemm_nt(p, vspw_stream(stream));
 }
 
@@ -1177,7 +1204,7 @@ extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, 
     p.part = splits > 1 ? reinterpret_cast<float*>(ws) : dw;
     p.nb = d->n; p.h = d->h; p.w = d->w; p.c = d->c;
     p.oh = d->oh; p.ow = d->ow;
-    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;
     p.k = d->k;
     p.ncols = d->kh * d->kw * d->c;
     long long P = (long long)d->n * d->oh * d->ow;
@@ -1198,7 +1225,7 @@ extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, 
     } else {
         // gather mode (see igemm_tn_v2_kernel)
         const bool same = d->stride == 1 && d->oh == d->h && d->ow == d->w;
-        const bool point = same && d->kh * d->kw == 1 && d->pad == 0;
+        const bool point = same && d->kh * d->kw == 1 && d->pad == 0 && d->pad_w == 0;
         const int g = point ? 3 : (same && p.ow >= BK) ? 2 : (p.ow >= BK ? 1 : 0);
         const int code = g * 100 + (tm / 64) * 10 + (tn / 64);
 #define TN_CASE(G, NB, WM_, WN_) \

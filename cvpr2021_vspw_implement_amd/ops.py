@@ -60,10 +60,12 @@ def empty_nhwc(n, c, h, w, device, dtype=torch.float32):
 
 
 def _conv_desc(x, k, kh, kw, stride, pad, dil):
+    """pad: int or (pad_h, pad_w) as in nn.Conv2d(padding=...)."""
     n, c, h, w = x.shape
-    oh = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
-    ow = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
-    return ConvDesc(n, h, w, c, oh, ow, k, kh, kw, stride, pad, dil)
+    ph, pw = (pad, pad) if isinstance(pad, int) else (int(pad[0]), int(pad[1]))
+    oh = (h + 2 * ph - dil * (kh - 1) - 1) // stride + 1
+    ow = (w + 2 * pw - dil * (kw - 1) - 1) // stride + 1
+    return ConvDesc(n, h, w, c, oh, ow, k, kh, kw, stride, ph, dil, pw)
 
 
 # Optional per-launch timing of the MFMA GEMM kernels (bench.py's roofline leg): HIP events are recorded on the

@@ -38,7 +38,8 @@ int vspw_abi_version(void);
 typedef struct vspw_conv_desc {
     int n, h, w, c;
     int oh, ow, k;
-    int kh, kw, stride, pad, dil;
+    int kh, kw, stride, pad, dil; /* pad: rows (H) on both sides */
+    int pad_w;                    /* columns (W) on both sides; nn.Conv2d(padding=(pad, pad_w)) */
 } vspw_conv_desc;
 
 /* y = conv2d(x, w) (+ bias).  Replaces F.conv2d at models/resnet.py:61-66,100-106,130 (after the hyper-parameter
@@ -49,6 +50,12 @@ typedef struct vspw_conv_desc {
 int vspw_conv2d_fwd(const vspw_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                     float* stat_part, void* stream);
 size_t vspw_conv2d_stats_partials(const vspw_conv_desc* d);
+/* Inference-side variant used by the frozen RAFT flow network (RAFT_core/update.py:6-136, extractor.py:6-190): the
+ * input may be a channel slice of a wider NHWC buffer (pixel stride ldx floats >= c; torch.cat call sites such as
+ * update.py:24,29,44,47 become slot writes), the output is written with row stride ldy floats >= k, and the epilogue
+ * applies act(conv + bias): 0 none, 1 relu, 2 sigmoid, 3 tanh (update.py:14,26-28,84-92). */
+int vspw_conv2d_fwd_ex(const vspw_conv_desc* d, const float* x, long long ldx, const float* w, const float* bias,
+                       int act, float* y, long long ldy, void* stream);
 /* dx = conv2d_backward_input(dy, w).  wT is the [c][kh][kw][k] copy of w made by vspw_weight_transpose. */
 int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, const float* wT, float* dx, void* stream);
 /* dw [k][kh][kw][c] = conv2d_backward_weight(dy, x); split-K over pixels, deterministic reduction. */
@@ -194,6 +201,36 @@ int vspw_chan_scale(const float* g, const float* w, float* out, long long rows, 
 int vspw_flowwarp_fwd(const float* x, const float* flow, float* y, int n, int h, int w, int c, void* stream);
 int vspw_flowwarp_bwd(const float* dy, const float* x, const float* flow, float* dx, float* dflow, int n, int h,
                       int w, int c, void* stream);
+
+/* ---------------------------------------------------------------- RAFT flow network (raft.hip) ----- */
+/* Forward-only kernels of the frozen RAFT that produces the flow consumed by vspw_flowwarp_fwd
+ * (models/netwarp.py:170-176 -> RAFT_core/raft.py:75-127, iters=20, test_mode=True).  Convolutions use
+ * vspw_conv2d_fwd_ex; the all-pairs correlation (RAFT_core/corr.py:54-62) is the same NT GEMM. */
+/* nn.InstanceNorm2d (no affine, eps) coefficients of x [n][hw][c], c <= 256: scale[n][c] = 1/sqrt(var+eps),
+ * shift[n][c] = -mean*scale  (RAFT_core/extractor.py:27-31,131). */
+size_t vspw_instance_norm_workspace(int n, int hw, int c);
+int vspw_instance_norm_coeffs(const float* x, int n, int hw, int c, float eps, float* scale, float* shift, void* ws,
+                              size_t ws_bytes, void* stream);
+/* y = [relu_out]( [residual +] [relu_in]( x*scale[img*coef_stride + ch] + shift[...] ) ): the norm -> relu ->
+ * (x + y) -> relu chain of RAFT_core/extractor.py:44-56; coef_stride = c for instance norm, 0 for eval BatchNorm. */
+int vspw_affine_act(const float* x, const float* scale, const float* shift, int coef_stride, const float* residual,
+                    int relu_in, int relu_out, float* y, int n, int hw, int c, void* stream);
+/* F.avg_pool2d(x, 2, stride=2) over the last two dims of [planes][h][w] (RAFT_core/corr.py:27-29). */
+int vspw_avgpool2x2(const float* in, float* out, long long planes, int h, int w, void* stream);
+/* CorrBlock.__call__ (RAFT_core/corr.py:31-52): for every pixel row = b*h1*w1 + i with centre (x_i, y_i) + flow[row],
+ * out[row][l*81 + a*9 + c] = bilinear sample (align_corners=True, zeros) of level l's [h1>>l][w1>>l] plane of that row
+ * at (cx/2^l + a - 4, cy/2^l + c - 4).  flow row stride ldf >= 2, out row stride ldo >= 324; h1, w1 >= 16. */
+int vspw_corr_lookup(const float* l0, const float* l1, const float* l2, const float* l3, const float* flow,
+                     long long ldf, float* out, long long ldo, int b, int h1, int w1, void* stream);
+/* SepConvGRU gates (RAFT_core/update.py:44-60); zr[row] = [z(c) | r(c)].  out = r*h;  h = (1-z)*h + z*q. */
+int vspw_gru_rh(const float* zr, long long ldzr, const float* h, long long ldh, float* out, long long ldo,
+                long long rows, int c, void* stream);
+int vspw_gru_update(const float* zr, long long ldzr, const float* q, long long ldq, float* h, long long ldh,
+                    long long rows, int c, void* stream);
+/* RAFT.upsample_flow (RAFT_core/raft.py:57-68): flow [n][h][w] rows of (fx, fy) (stride ldf), mask [n][h][w][576]
+ * (stride ldm, channel = k*64 + i*8 + j), softmax over k of mask_scale*mask; out NCHW [n][2][8h][8w]. */
+int vspw_convex_upsample(const float* flow, long long ldf, const float* mask, long long ldm, float mask_scale,
+                         float* out, int n, int h, int w, void* stream);
 
 /* torch.optim.SGD(momentum, weight_decay) update applied `mult` times with the same gradient (the reference's
  * parameter-group generators yield a parameter once per enclosing module, train_clip2.py:215-236 +

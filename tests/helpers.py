@@ -138,3 +138,17 @@ def calibrate_bn_hip(module, run_train_forward):
         run_train_forward()
     for m in bns:
         m.momentum = 0.1
+
+
+# ------------------------------------------------------------------------------------------------------ RAFT
+def raft_images(tag, shape):
+    """Same two frames as tools/make_golden.py:raft_images."""
+    a = np.clip(det_input(tag + ":img1", shape) * 60.0 + 120.0, 0.0, 255.0).astype(np.float32)
+    b = np.roll(a, (2, -3), axis=(2, 3)) + det_input(tag + ":noise", shape) * 4.0
+    return a, np.clip(b, 0.0, 255.0).astype(np.float32)
+
+
+def raft_state(fx):
+    """Deterministic RAFT weights keyed by the reference's state_dict names (stored in the fixture)."""
+    return {str(k): det_tensor(str(k), tuple(int(d) for d in str(s).split(",")) if str(s) else ())
+            for k, s in zip(fx["sd_keys"], fx["sd_shapes"])}

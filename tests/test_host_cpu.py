@@ -128,10 +128,10 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert _C.load(check_symbols=True).vspw_abi_version() == 1
     # workspace queries are pure host functions: exercise the ABI without a GPU
-    d = _C.ConvDesc(10, 60, 60, 256, 60, 60, 256, 3, 3, 1, 2, 2)
+    d = _C.ConvDesc(10, 60, 60, 256, 60, 60, 256, 3, 3, 1, 2, 2, 2)
     assert _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d)) > 0
     assert _C.query("vspw_conv2d_stats_partials", ctypes.byref(d)) in ((36000 + 127) // 128, 36000 // 96, (36000 + 63) // 64)
-    bad = _C.ConvDesc(10, 60, 60, 256, 61, 60, 256, 3, 3, 1, 2, 2)
+    bad = _C.ConvDesc(10, 60, 60, 256, 61, 60, 256, 3, 3, 1, 2, 2, 2)
     assert _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(bad)) == 0
     assert _C.load().vspw_conv2d_fwd(ctypes.byref(bad), None, None, None, None, None, None) == -1
 

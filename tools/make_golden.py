@@ -361,6 +361,48 @@ def case_netwarp(M, arch, tag, shape=(2, 3, 65, 65)):
     print(tag, "loss %.6f acc %.4f" % (loss.item(), acc.item()))
 
 
+def raft_images(tag, shape):
+    """Two frames in [0, 255]: smooth-ish random texture and a shifted, perturbed copy."""
+    a = np.clip(det_input(tag + ":img1", shape) * 60.0 + 120.0, 0.0, 255.0).astype(np.float32)
+    b = np.roll(a, (2, -3), axis=(2, 3)) + det_input(tag + ":noise", shape) * 4.0
+    return a, np.clip(b, 0.0, 255.0).astype(np.float32)
+
+
+def case_raft(tag="raft_basic", shape=(1, 3, 128, 192), iters=4):
+    """The frozen flow network of NetWarp (models/netwarp.py:71-77,170-176): RAFT_core.raft.RAFT in eval mode with
+    deterministic weights, test_mode=True (fp32; the reference's forward casts to float32 internally, raft.py:92-93,
+    so there is no float64 re-run here - the oracle's own fp64-vs-fp32 gap is the noise estimate in the tests)."""
+    from RAFT_core.corr import CorrBlock
+    from RAFT_core.raft import RAFT
+
+    torch.manual_seed(0)
+    raft = RAFT()
+    load_det(raft)
+    raft.eval()
+    a, b = raft_images(tag, shape)
+    res = {}
+    with torch.no_grad():
+        ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+        for it in (1, iters):
+            low, up = raft(ta, tb, iters=it, test_mode=True)
+            res["flow_low_it%d" % it] = low.numpy()
+            res["flow_up_it%d" % it] = up.numpy()
+        i1, i2 = 2 * (ta / 255.0) - 1.0, 2 * (tb / 255.0) - 1.0
+        f1, f2 = raft.fnet([i1, i2])
+        res["fmap1"] = f1.numpy()
+        res["cnet"] = raft.cnet(i1).numpy()
+        n, _, h, w = f1.shape
+        ys, xs = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        coords = torch.stack([xs, ys], 0).float()[None].repeat(n, 1, 1, 1)
+        res["corr0"] = CorrBlock(f1.float(), f2.float(), radius=4)(coords + 0.37).numpy()
+    sd = raft.state_dict()
+    res["sd_keys"] = np.array(list(sd.keys()))
+    res["sd_shapes"] = np.array([",".join(str(int(d)) for d in v.shape) for v in sd.values()])
+    res["meta"] = np.array([str(shape), str(iters)])
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, "flow_low |max| %.3f" % np.abs(res["flow_low_it%d" % iters]).max())
+
+
 def case_ops(M, tag="ops_reference"):
     """Op-level vectors straight from the reference's own helper functions."""
     import models.netwarp as ref_nw
@@ -491,6 +533,8 @@ def main():
         case_clip(M, "clip_psp", "resnet50dilated", "r50_clip_psp_pspw", psp_weight=True)
     if want("r50_clip_ocr_memory"):
         case_ocr_memory(M, "resnet50dilated", "r50_clip_ocr_memory")
+    if want("raft_basic"):
+        case_raft()
 
 
 if __name__ == "__main__":

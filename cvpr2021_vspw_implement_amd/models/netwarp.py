@@ -1,9 +1,10 @@
 """NetWarp (optical-flow feature warping), mirroring reference models/netwarp.py:12-239.
 
-`flowwarp` and the per-channel blend run on the HIP kernels (csrc/misc.hip).  RAFT itself is the frozen flow provider
-(SURVEY.md §2 "◐", §8f rank 1): it stays on stock PyTorch-ROCm ops and is NOT part of this package — NetWarp takes
-it from `args.flow_net` (any nn.Module with RAFT's forward(img1, img2, iters, test_mode) -> (low, up) signature), or
-imports the reference's own RAFT_core when that package and its checkpoint are on the path.
+`flowwarp` and the per-channel blend run on the HIP kernels (csrc/misc.hip).  The frozen flow provider is RAFT on the
+HIP kernels as well (models/raft.py + csrc/raft.hip); like the reference (netwarp.py:71-77) it
+is built in the constructor and filled from `./RAFT_core/raft-things.pth-no-zip`.  `args.raft_weights` overrides the
+checkpoint path ('' / None: keep the random initialisation - benchmarks, tests); `args.flow_net` substitutes any
+nn.Module with RAFT's forward(img1, img2, iters, test_mode) -> (low, up) signature.
 """
 import torch
 import torch.nn as nn
@@ -41,26 +42,25 @@ def _load_flow_net(args):
     net = getattr(args, "flow_net", None)
     if net is not None:
         return net
-    try:
-        from RAFT_core.raft import RAFT  # the reference's vendored RAFT (stock PyTorch ops), if on sys.path
-    except Exception as e:  # pragma: no cover - depends on the deployment
-        raise NotImplementedError(
-            "NetWarp needs an optical-flow network: pass args.flow_net or put the reference's RAFT_core (with "
-            "raft-things.pth-no-zip) on sys.path (%s)" % (e,))
     from collections import OrderedDict
 
+    from .raft import RAFT
+
     raft = RAFT()
-    to_load = torch.load("./RAFT_core/raft-things.pth-no-zip")
-    raft.load_state_dict(OrderedDict((k[7:], v) for k, v in to_load.items()))
+    weights = getattr(args, "raft_weights", "./RAFT_core/raft-things.pth-no-zip")
+    if weights:
+        to_load = torch.load(weights, map_location="cpu")
+        raft.load_state_dict(OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in to_load.items()))
     return raft
 
 
 def _pad_to_8(x):
-    """RAFT's InputPadder('sintel') (RAFT_core/utils/utils.py:7-25): replicate-pad H,W up to multiples of 8."""
+    """RAFT's InputPadder('sintel') (RAFT_core/utils/utils.py:7-25): zero-pad H,W up to multiples of 8 (the
+    reference's replicate mode is commented out, utils.py:19-20: mode='constant')."""
     h, w = x.shape[-2:]
     ph, pw = (((h // 8) + 1) * 8 - h) % 8, (((w // 8) + 1) * 8 - w) % 8
     pad = [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]
-    return F.pad(x, pad, mode="replicate"), pad
+    return F.pad(x, pad, mode="constant"), pad
 
 
 class _NetWarpBase(LrGroupsMixin, nn.Module):

@@ -1,0 +1,34 @@
+"""Time the frozen RAFT flow network on the HIP kernels as NetWarp runs it: B=2 frame pairs, 480x856 (479x853 zero-padded
+to multiples of 8), iters=20, test_mode=True.  Prints one JSON line (ms per forward, frame pairs / s)."""
+import json
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from cvpr2021_vspw_implement_amd.models.raft import RAFT  # noqa: E402
+
+
+def main():
+    B, H, W, iters = 2, 480, 856, 20
+    dev = torch.device("cuda:0")
+    torch.manual_seed(304)
+    m = RAFT().to(dev).eval()
+    a = (torch.rand(B, 3, H, W, device=dev) * 255).float()
+    b = torch.roll(a, (3, -2), (2, 3))
+    for _ in range(2):
+        m(a, b, iters=iters, test_mode=True)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        low, up = m(a, b, iters=iters, test_mode=True)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    print(json.dumps({"workload": "RAFT-basic forward, B=2 pairs, 480x856, iters=20", "ms_per_forward": round(ms, 2),
+                      "pairs_per_s": round(B / ms * 1e3, 2), "finite": bool(torch.isfinite(up).all().item())}))
+
+
+if __name__ == "__main__":
+    main()

@@ -593,6 +593,9 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
     } else if (cfg == 12) {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
         hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
+    } else if (cfg == 21) {
+        int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
     } else {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
         hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
@@ -608,7 +611,7 @@ static int nt_decide(const IgemmNT& p, bool& v2) {
     // 32-bit byte offsets relative to the first image a tile touches / the tile's first weight row
     const long long img_elems = (long long)p.h * p.w * p.lds;
     const long long span = (128 / ((long long)p.oh * p.ow) + 2) * img_elems;
-    v2 = cfg != 21 && p.vec && p.c % BK == 0 && span < (1LL << 30) && (long long)p.kdim < (1LL << 22) &&
+    v2 = p.vec && p.c % BK == 0 && span < (1LL << 30) && (long long)p.kdim < (1LL << 22) &&
          (p.mode == 0 || p.stride == 1);
     if (!v2 && cfg == 31) cfg = 12;  // the generic kernel has no 96-row instantiation
     return cfg;

@@ -12,20 +12,24 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------ instance norm
-// partial[n][chunk][2][c]: per row-chunk column sums of x and x*x of image n.
+// partial[n][chunk][2][c]: per row-chunk column sums of x and x*x of image n.  float4 lanes along the channels
+// (c % 4 == 0), 256 / (c/4) row lanes; a chunk is INORM_ROWS rows so that even the half-resolution maps give > 1000
+// workgroups.
+#define INORM_ROWS 256
 __global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restrict__ x, float* __restrict__ partial,
-                                                          int hw, int c, int rows_per_chunk) {
-    __shared__ float red[2][256];
+                                                          int hw, int c) {
+    __shared__ f32x4 red[2][256];
     const int n = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
     const int tid = threadIdx.x;
-    const int row_lanes = 256 / c > 0 ? 256 / c : 1;  // c <= 256 on this path (host check)
-    const int ch = tid % c, rl = tid / c;
-    const int r0 = chunk * rows_per_chunk, r1 = min(hw, r0 + rows_per_chunk);
-    float s = 0.f, q = 0.f;
+    const int lanes_c = c >> 2;
+    const int row_lanes = 256 / lanes_c;
+    const int cl = tid % lanes_c, rl = tid / lanes_c;
+    const int r0 = chunk * INORM_ROWS, r1 = min(hw, r0 + INORM_ROWS);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = {0.f, 0.f, 0.f, 0.f};
     if (rl < row_lanes) {
-        const float* xp = x + (size_t)n * hw * c + ch;
+        const f32x4* xp = reinterpret_cast<const f32x4*>(x + (size_t)n * hw * c) + cl;
         for (int r = r0 + rl; r < r1; r += row_lanes) {
-            const float v = xp[(size_t)r * c];
+            const f32x4 v = xp[(size_t)r * lanes_c];
             s += v;
             q += v * v;
         }
@@ -33,36 +37,52 @@ __global__ __launch_bounds__(256) void inorm_stats_kernel(const float* __restric
     red[0][tid] = s;
     red[1][tid] = q;
     __syncthreads();
-    if (tid < c) {
-        float ss = 0.f, qq = 0.f;
+    if (tid < lanes_c) {
+        f32x4 ss = {0.f, 0.f, 0.f, 0.f}, qq = {0.f, 0.f, 0.f, 0.f};
         for (int l = 0; l < row_lanes; ++l) {
-            ss += red[0][l * c + tid];
-            qq += red[1][l * c + tid];
+            ss += red[0][l * lanes_c + tid];
+            qq += red[1][l * lanes_c + tid];
         }
         float* out = partial + ((size_t)n * nchunk + chunk) * 2 * c;
-        out[tid] = ss;
-        out[c + tid] = qq;
+        reinterpret_cast<f32x4*>(out)[tid] = ss;
+        reinterpret_cast<f32x4*>(out + c)[tid] = qq;
     }
 }
 
 // scale[n][c] = 1/sqrt(var_biased + eps), shift[n][c] = -mean*scale  (nn.InstanceNorm2d defaults: no affine, no
-// running statistics, eps 1e-5; extractor.py:27-31,131).  fp64 combine of the fp32 chunk partials.
-__global__ void inorm_finalize_kernel(const float* __restrict__ partial, float* __restrict__ scale,
-                                      float* __restrict__ shift, int nchunk, int hw, int c, float eps) {
-    const int n = blockIdx.x;
-    for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
-        double s = 0.0, q = 0.0;
-        for (int k = 0; k < nchunk; ++k) {
+// running statistics, eps 1e-5; extractor.py:27-31,131).  fp64 combine of the fp32 chunk partials: one workgroup per
+// image, 256 / c chunk lanes per channel.
+__global__ __launch_bounds__(256) void inorm_finalize_kernel(const float* __restrict__ partial,
+                                                             float* __restrict__ scale, float* __restrict__ shift,
+                                                             int nchunk, int hw, int c, float eps) {
+    __shared__ double red[2][256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int lanes = 256 / c;  // c <= 256
+    const int ch = tid % c, ln = tid / c;
+    double s = 0.0, q = 0.0;
+    if (ln < lanes) {
+        for (int k = ln; k < nchunk; k += lanes) {
             const float* p = partial + ((size_t)n * nchunk + k) * 2 * c;
             s += (double)p[ch];
             q += (double)p[c + ch];
+        }
+    }
+    red[0][tid] = s;
+    red[1][tid] = q;
+    __syncthreads();
+    if (tid < c) {
+        s = 0.0;
+        q = 0.0;
+        for (int l = 0; l < lanes; ++l) {
+            s += red[0][l * c + tid];
+            q += red[1][l * c + tid];
         }
         const double mean = s / hw;
         double var = q / hw - mean * mean;
         if (var < 0.0) var = 0.0;
         const float inv = (float)(1.0 / sqrt(var + (double)eps));
-        scale[(size_t)n * c + ch] = inv;
-        shift[(size_t)n * c + ch] = (float)(-mean) * inv;
+        scale[(size_t)n * c + tid] = inv;
+        shift[(size_t)n * c + tid] = (float)(-mean) * inv;
     }
 }
 
@@ -71,19 +91,24 @@ __global__ void inorm_finalize_kernel(const float* __restrict__ partial, float* 
 __global__ __launch_bounds__(256) void affine_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          const float* __restrict__ res, float* __restrict__ y,
-                                                         long long total, int hw, int c, int coef_stride,
+                                                         long long total4, int hw, int c, int coef_stride,
                                                          int relu_in, int relu_out) {
+    // float4 lanes (c % 4 == 0); 32-bit index math per element group
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    const long long per_img = (long long)hw * c;
-    for (; i < total; i += stride) {
-        const int ch = (int)(i % c);
-        const long long img = i / per_img;
-        float v = x[i] * scale[img * coef_stride + ch] + shift[img * coef_stride + ch];
-        if (relu_in) v = fmaxf(v, 0.f);
-        if (res) v += res[i];
-        if (relu_out) v = fmaxf(v, 0.f);
-        y[i] = v;
+    const int c4 = c >> 2;
+    const long long per_img4 = (long long)hw * c4;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (; i < total4; i += stride) {
+        const long long img = i / per_img4;
+        const int ch = (int)((i - img * per_img4) % c4) * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + img * coef_stride + ch);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + img * coef_stride + ch);
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i] * sc + sh;
+        if (relu_in) v = __builtin_elementwise_max(v, zero);
+        if (res) v += reinterpret_cast<const f32x4*>(res)[i];
+        if (relu_out) v = __builtin_elementwise_max(v, zero);
+        reinterpret_cast<f32x4*>(y)[i] = v;
     }
 }
 
@@ -225,18 +250,18 @@ __global__ __launch_bounds__(64) void convex_upsample_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------------- C ABI
 extern "C" size_t vspw_instance_norm_workspace(int n, int hw, int c) {
     if (n <= 0 || hw <= 0 || c <= 0) return 0;
-    const int nchunk = (hw + 1023) / 1024;
+    const int nchunk = (hw + INORM_ROWS - 1) / INORM_ROWS;
     return (size_t)n * nchunk * 2 * c * sizeof(float);
 }
 
 extern "C" int vspw_instance_norm_coeffs(const float* x, int n, int hw, int c, float eps, float* scale, float* shift,
                                          void* ws, size_t ws_bytes, void* stream) {
-    if (!x || !scale || !shift || n <= 0 || hw <= 0 || c <= 0 || c > 256) return VSPW_EINVAL;
-    const int nchunk = (hw + 1023) / 1024;
+    if (!x || !scale || !shift || n <= 0 || hw <= 0 || c <= 0 || c > 256 || (c & 3)) return VSPW_EINVAL;
+    const int nchunk = (hw + INORM_ROWS - 1) / INORM_ROWS;
     if (!ws || ws_bytes < (size_t)n * nchunk * 2 * c * sizeof(float)) return VSPW_EINVAL;
     float* part = reinterpret_cast<float*>(ws);
     hipStream_t st = vspw_stream(stream);
-    hipLaunchKernelGGL(inorm_stats_kernel, dim3(nchunk, n), dim3(256), 0, st, x, part, hw, c, 1024);
+    hipLaunchKernelGGL(inorm_stats_kernel, dim3(nchunk, n), dim3(256), 0, st, x, part, hw, c);
     hipLaunchKernelGGL(inorm_finalize_kernel, dim3(n), dim3(256), 0, st, part, scale, shift, nchunk, hw, c, eps);
     return vspw_launch_status();
 }
@@ -244,10 +269,11 @@ extern "C" int vspw_instance_norm_coeffs(const float* x, int n, int hw, int c, f
 extern "C" int vspw_affine_act(const float* x, const float* scale, const float* shift, int coef_stride,
                                const float* residual, int relu_in, int relu_out, float* y, int n, int hw, int c,
                                void* stream) {
-    if (!x || !scale || !shift || !y || n <= 0 || hw <= 0 || c <= 0 || coef_stride < 0) return VSPW_EINVAL;
-    const long long total = (long long)n * hw * c;
-    hipLaunchKernelGGL(affine_act_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream), x, scale,
-                       shift, residual, y, total, hw, c, coef_stride, relu_in, relu_out);
+    if (!x || !scale || !shift || !y || n <= 0 || hw <= 0 || c <= 0 || (c & 3) || coef_stride < 0 || (coef_stride & 3))
+        return VSPW_EINVAL;
+    const long long total4 = (long long)n * hw * (c >> 2);
+    hipLaunchKernelGGL(affine_act_kernel, dim3(vspw_stream_grid(total4, 256)), dim3(256), 0, vspw_stream(stream), x, scale,
+                       shift, residual, y, total4, hw, c, coef_stride, relu_in, relu_out);
     return vspw_launch_status();
 }
 

@@ -1,12 +1,13 @@
 """Time the frozen RAFT flow network on the HIP kernels as NetWarp runs it: B=2 frame pairs, 480x856 (479x853 zero-padded
 to multiples of 8), iters=20, test_mode=True.  Prints one JSON line (ms per forward, frame pairs / s)."""
 import json
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cvpr2021_vspw_implement_amd.models.raft import RAFT  # noqa: E402
 
 

@@ -232,6 +232,25 @@ int vspw_gru_update(const float* zr, long long ldzr, const float* q, long long l
 int vspw_convex_upsample(const float* flow, long long ldf, const float* mask, long long ldm, float mask_scale,
                          float* out, int n, int h, int w, void* stream);
 
+/* ---------------------------------------------------------------- input pipeline (data.hip) ------- */
+/* Device side of the reference's dataset transforms (dataset2.py:852-1048 BaseDataset_longclip, :657-850
+ * BaseDataset_clip, :154-490 test datasets) on decoded uint8 frames resident in HBM. */
+/* One separable pass of Pillow's 8-bit resampler (Image.resize(BILINEAR), dataset2.py:1024): bounds[o] = (first,
+ * count), kk[o][ksize] = Pillow's 22-bit fixed-point coefficients (host tables, device memory); axis 0 resamples
+ * columns (out_h == in_h), axis 1 rows (out_w == in_w).  in/out: interleaved [h][w][channels] u8.  flip != 0 reads
+ * the source mirrored along x (the reference flips the PIL image before it resizes it, dataset2.py:1015-1017). */
+int vspw_resample_u8(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* kk, int ksize, int in_h,
+                     int in_w, int out_h, int out_w, int channels, int axis, int flip, void* stream);
+/* Image.resize(NEAREST) of the label map (dataset2.py:1025): out[y][x] = in[ytab[y]][xtab[x]]. */
+int vspw_gather_u8(const uint8_t* in, uint8_t* out, const int32_t* xtab, const int32_t* ytab, int in_w, int out_h,
+                   int out_w, int flip, void* stream);
+/* flip + zero/255 pad + crop + /255 + Normalize(mean, std) + NHWC, and the label remap 0->255, v->v-1 as float
+ * (dataset2.py:921-947,964-977), into one frame slot of the batch: img_out [out_h][out_w][3], lab_out
+ * [out_h][out_w] (either may be NULL; lab may be NULL).  mean3 / std3 are HOST pointers to 3 floats. */
+int vspw_frame_transform(const uint8_t* img, const uint8_t* lab, int h, int w, int flip, int pad_h, int pad_w,
+                         int crop_y, int crop_x, int out_h, int out_w, const float* mean3, const float* std3,
+                         float* img_out, float* lab_out, void* stream);
+
 /* torch.optim.SGD(momentum, weight_decay) update applied `mult` times with the same gradient (the reference's
  * parameter-group generators yield a parameter once per enclosing module, train_clip2.py:215-236 +
  * models/clip_psp.py:99-135).  p, g, buf are dense tensors with identical strides; first != 0 initialises buf. */

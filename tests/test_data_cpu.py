@@ -1,0 +1,117 @@
+"""Input pipeline, host side (CPU): the dataset mirrors (cvpr2021_vspw_implement_amd/dataset2.py) must pick the same
+frames, flip, scale and crop window as the reference's dataset2.py classes under the same seeds, and the numpy/PIL
+restatement of the pixel chain (oracle/det_data.py) must reproduce the reference's tensors bit for bit
+(tests/golden/vspw_datasets.npz, made by running the reference's classes on the same tiny VSPW tree).  Also pins the
+host-computed Pillow resampling tables against PIL itself."""
+import random
+
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle.det_data import make_tiny_vspw, np_frame_transform
+
+from helpers import args_ns, golden
+
+
+@pytest.fixture(scope="module")
+def tree(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("vspw_tiny"))
+    make_tiny_vspw(root)
+    return root
+
+
+def _apply_oracle(sample):
+    sp = sample.spec
+    crop = None
+    if (sp.out_h, sp.out_w) != (sp.new_h, sp.new_w) or sp.pad_h or sp.pad_w or sp.crop_y or sp.crop_x:
+        crop = (sp.pad_h, sp.pad_w, sp.crop_y, sp.crop_x, sp.out_h, sp.out_w)
+    outs = [np_frame_transform(f, m, sp.flip, (sp.new_h, sp.new_w), crop) for f, m in zip(sample.frames, sample.masks)]
+    return np.stack([o[0] for o in outs]), np.stack([o[1] for o in outs])
+
+
+def _check(fx, key, sample):
+    imgs, labs = _apply_oracle(sample)
+    assert imgs.shape == fx[key + ":imgs"].shape, key
+    assert np.array_equal(imgs, fx[key + ":imgs"]), key
+    assert np.array_equal(labs, fx[key + ":labs"]), key
+
+
+def test_train_datasets_draw_and_transform_like_the_reference(tree):
+    import cvpr2021_vspw_implement_amd.dataset2 as D
+
+    fx = golden("vspw_datasets")
+    seen_flip, seen_scale = set(), set()
+    for ms in (False, True):
+        a = args_ns(cropsize=40, dataroot=tree, trainfps=1, clip_num=4, dilation2="3,6,9", multi_scale=ms,
+                    lesslabel=False, dilation_num=0, method="clip_psp")
+        ds = D.BaseDataset_longclip(a, "train")
+        assert len(ds) == 3
+        for seed in (0, 1, 2, 3, 4):
+            np.random.seed(100 + seed)
+            random.seed(200 + seed)
+            s = ds[seed % len(ds)]
+            seen_flip.add(s.spec.flip)
+            seen_scale.add((s.spec.new_h, s.spec.new_w) != s.frames[0].shape[:2])
+            _check(fx, "longclip:ms%d:seed%d" % (ms, seed), s)
+    assert seen_flip == {0, 1} and seen_scale == {False, True}  # the cases exercise flip and rescale
+    a = args_ns(cropsize=40, dataroot=tree, trainfps=1, clip_num=2, dilation_num=0, multi_scale=True, lesslabel=False,
+                method="netwarp")
+    ds = D.BaseDataset_clip(a, "train")
+    for seed in (0, 1, 2):
+        np.random.seed(300 + seed)
+        random.seed(400 + seed)
+        _check(fx, "clip:seed%d" % seed, ds[seed % len(ds)])
+
+
+def test_test_datasets_like_the_reference(tree):
+    import cvpr2021_vspw_implement_amd.dataset2 as D
+
+    fx = golden("vspw_datasets")
+    a = args_ns(clip_num=4, dilation2="3,6,9", lesslabel=False, method="clip_psp")
+    ts = D.TestDataset_longclip(tree, "v_b", a, is_train=False)
+    assert len(ts) == int(fx["test_longclip:len"])
+    for index in (0, 7):  # 7: offsets mirrored backwards near the end of the video
+        s = ts[index]
+        assert s.names == str(fx["test_longclip:%d:name" % index])
+        _check(fx, "test_longclip:%d" % index, s)
+    a = args_ns(clip_num=3, dilation_num=1, lesslabel=False, method="netwarp")
+    tc = D.TestDataset_clip(tree, "v_c", a, is_train=False)
+    for index in (0, 9, 19):  # both clamped ends and the interior
+        _check(fx, "test_clip:%d" % index, tc[index])
+    a = args_ns(clip_num=3, dilation_num=1, lesslabel=False, method="nonlocal3d")
+    tn = D.TestDataset_clip(tree, "v_c", a, is_train=True)
+    assert len(tn) == int(fx["test_clip_nl3d:len"])
+    s = tn[1]
+    assert list(s.names) == [str(n) for n in fx["test_clip_nl3d:1:names"]]
+    _check(fx, "test_clip_nl3d:1", s)
+
+
+@pytest.mark.parametrize("h,w,scale", [(36, 52, 0.8), (36, 52, 1.5), (50, 64, 2.0), (480, 853, 0.8), (97, 131, 1.5)])
+def test_pillow_tables_reproduce_pil_resize(h, w, scale):
+    """The integer coefficient / index tables the device kernels consume, applied with numpy integer arithmetic
+    exactly as csrc/data.hip does, equal PIL's Image.resize bit for bit."""
+    from cvpr2021_vspw_implement_amd.dataset2 import pil_bilinear_tables, pil_nearest_table
+
+    rs = np.random.RandomState(h * 1000 + w)
+    img = rs.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+    seg = rs.randint(0, 125, size=(h, w)).astype(np.uint8)
+    nh, nw = int(h * scale), int(w * scale)
+
+    def one_pass(a, bounds, kk, axis):
+        a = np.moveaxis(a.astype(np.int64), axis, 0)
+        out = np.empty((bounds.shape[0],) + a.shape[1:], np.int64)
+        for o in range(bounds.shape[0]):
+            lo, n = bounds[o]
+            acc = np.tensordot(kk[o, :n].astype(np.int64), a[lo:lo + n], axes=(0, 0)) + (1 << 21)
+            out[o] = np.clip(acc >> 22, 0, 255)
+        return np.moveaxis(out, 0, axis).astype(np.uint8)
+
+    bx, kx, _ = pil_bilinear_tables(w, nw)
+    by, ky, _ = pil_bilinear_tables(h, nh)
+    got = one_pass(one_pass(img, bx, kx, 1), by, ky, 0)
+    ref = np.array(Image.fromarray(img, "RGB").resize((nw, nh), Image.BILINEAR))
+    assert np.array_equal(got, ref)
+    xt, yt = pil_nearest_table(w, nw), pil_nearest_table(h, nh)
+    ref = np.array(Image.fromarray(seg, "L").resize((nw, nh), Image.NEAREST))
+    assert np.array_equal(seg[yt][:, xt], ref)

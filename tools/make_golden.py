@@ -27,8 +27,26 @@ OUT = os.path.join(ROOT, "tests", "golden")
 K = 124
 
 
+class _Normalize(object):
+    """torchvision.transforms.Normalize (functional.normalize: sub_(mean[:,None,None]).div_(std[:,None,None]) in the
+    tensor's dtype) - torchvision itself is not installed here."""
+
+    def __init__(self, mean, std):
+        self.mean, self.std = mean, std
+
+    def __call__(self, t):
+        t = t.clone()
+        m = torch.as_tensor(self.mean, dtype=t.dtype)
+        s = torch.as_tensor(self.std, dtype=t.dtype)
+        return t.sub_(m[:, None, None]).div_(s[:, None, None])
+
+
 def import_reference():
-    sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+    tv = sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+    if not hasattr(tv, "transforms"):
+        tv.transforms = types.ModuleType("torchvision.transforms")
+        tv.transforms.Normalize = _Normalize
+        sys.modules["torchvision.transforms"] = tv.transforms
     sys.path.insert(0, REF)
     sys.path.insert(0, os.path.join(REF, "RAFT_core"))
     cwd = os.getcwd()
@@ -403,6 +421,62 @@ def case_raft(tag="raft_basic", shape=(1, 3, 128, 192), iters=4):
     print(tag, "flow_low |max| %.3f" % np.abs(res["flow_low_it%d" % iters]).max())
 
 
+def case_datasets(tag="vspw_datasets"):
+    """The reference's dataset classes (dataset2.py) on the tiny deterministic VSPW tree of oracle/det_data.py: which
+    frames / flip / scale / crop the seeded draws select, and the tensors the model would be fed."""
+    import random
+    import tempfile
+
+    import dataset2 as D
+    from oracle.det_data import make_tiny_vspw
+
+    root = tempfile.mkdtemp(prefix="vspw_tiny_")
+    make_tiny_vspw(root)
+    res = {}
+
+    def put(key, out):
+        imgs, labs = out[0], out[1]
+        res[key + ":imgs"] = np.stack([t.numpy() for t in imgs])
+        res[key + ":labs"] = np.stack([t.numpy() for t in labs])
+
+    for ms in (False, True):
+        a = args_ns(cropsize=40, dataroot=root, trainfps=1, clip_num=4, dilation2="3,6,9", multi_scale=ms,
+                    lesslabel=False, dilation_num=0, method="clip_psp")
+        ds = D.BaseDataset_longclip(a, "train")
+        for seed in (0, 1, 2, 3, 4):
+            np.random.seed(100 + seed)
+            random.seed(200 + seed)
+            idx = seed % len(ds)
+            put("longclip:ms%d:seed%d" % (ms, seed), ds[idx])
+    a = args_ns(cropsize=40, dataroot=root, trainfps=1, clip_num=2, dilation_num=0, multi_scale=True, lesslabel=False,
+                method="netwarp")
+    ds = D.BaseDataset_clip(a, "train")
+    for seed in (0, 1, 2):
+        np.random.seed(300 + seed)
+        random.seed(400 + seed)
+        put("clip:seed%d" % seed, ds[seed % len(ds)])
+    a = args_ns(clip_num=4, dilation2="3,6,9", lesslabel=False, method="clip_psp")
+    ts = D.TestDataset_longclip(root, "v_b", a, is_train=False)
+    for index in (0, 7):
+        img, tgt, cimgs, ctgts, name = ts[index]
+        put("test_longclip:%d" % index, ([img] + cimgs, [tgt] + ctgts))
+        res["test_longclip:%d:name" % index] = np.array(name)
+    res["test_longclip:len"] = np.int64(len(ts))
+    a = args_ns(clip_num=3, dilation_num=1, lesslabel=False, method="netwarp")
+    tc = D.TestDataset_clip(root, "v_c", a, is_train=False)
+    for index in (0, 9, 19):
+        img, tgt, cimgs, ctgts, name = tc[index]
+        put("test_clip:%d" % index, ([img] + cimgs, [tgt] + ctgts))
+    a = args_ns(clip_num=3, dilation_num=1, lesslabel=False, method="nonlocal3d")
+    tn = D.TestDataset_clip(root, "v_c", a, is_train=True)
+    img, tgt, cimgs, ctgts, names = tn[1]
+    put("test_clip_nl3d:1", ([img] + cimgs, [tgt] + ctgts))
+    res["test_clip_nl3d:1:names"] = np.array(names)
+    res["test_clip_nl3d:len"] = np.int64(len(tn))
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, len(res), "arrays")
+
+
 def case_ops(M, tag="ops_reference"):
     """Op-level vectors straight from the reference's own helper functions."""
     import models.netwarp as ref_nw
@@ -535,6 +609,8 @@ def main():
         case_ocr_memory(M, "resnet50dilated", "r50_clip_ocr_memory")
     if want("raft_basic"):
         case_raft()
+    if want("vspw_datasets"):
+        case_datasets()
 
 
 if __name__ == "__main__":

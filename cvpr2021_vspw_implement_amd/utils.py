@@ -78,3 +78,62 @@ def get_common(gt_list, pred_list, clip_num, h, w):
             pr_same &= pred_list[i] == pred_list[i + j]
         accs.append((pr_same & gt_same).sum() / gt_same.sum())
     return accs
+
+
+# ------------------------------------------------------------------------------------------- driver conveniences
+def parse_devices(input_devices):
+    """utils.py:282-302: '0-3' / '0,1' / 'gpu0-gpu2' -> ['gpu0', 'gpu1', ...] without duplicates."""
+    import re
+
+    ret = []
+    for d in input_devices.split(","):
+        d = d.lower().strip()
+        m = re.match(r"^(?:gpu)?(\d+)$", d)
+        if m:
+            found = [int(m.group(1))]
+        else:
+            m = re.match(r"^(?:gpu)?(\d+)-(?:gpu)?(\d+)$", d)
+            if not m:
+                raise ValueError('Can not recognize device: "{}"'.format(d))
+            a, b = int(m.group(1)), int(m.group(2))
+            if a > b:
+                a, b = b, a
+            found = list(range(a, b + 1))
+        for x in found:
+            if "gpu%d" % x not in ret:
+                ret.append("gpu%d" % x)
+    return ret
+
+
+def setup_logger(distributed_rank=0, filename="log.txt"):
+    """utils.py:110-122: stdout logger on the master process only."""
+    import logging
+    import sys
+
+    logger = logging.getLogger("Logger")
+    logger.setLevel(logging.DEBUG)
+    if distributed_rank > 0 or logger.handlers:
+        return logger
+    ch = logging.StreamHandler(stream=sys.stdout)
+    ch.setLevel(logging.DEBUG)
+    ch.setFormatter(logging.Formatter("[%(asctime)s %(levelname)s %(filename)s line %(lineno)d %(process)d] %(message)s"))
+    logger.addHandler(ch)
+    return logger
+
+
+def vspw_palette():
+    """The 256-entry palette test_clip2.py:25 writes into saved predictions: the 22 PASCAL-style colours the reference
+    lists (with 191 where VOC has 192), then grey (i, i, i)."""
+    pal = []
+    for i in range(256):
+        if i >= 22:
+            pal += [i, i, i]
+            continue
+        c, r, g, b = i, 0, 0, 0
+        for j in range(8):
+            r |= ((c >> 0) & 1) << (7 - j)
+            g |= ((c >> 1) & 1) << (7 - j)
+            b |= ((c >> 2) & 1) << (7 - j)
+            c >>= 3
+        pal += [191 if v == 192 else v for v in (r, g, b)]
+    return pal

@@ -1,0 +1,81 @@
+"""End-to-end run of the driver mirrors on the tiny VSPW tree: train_clip2.main (decode -> device input pipeline ->
+Clip_PSP / NetWarp step -> fused SGD -> checkpoint with the reference's key format) and test_clip2.main (checkpoint
+load, per-video inference, Evaluator / video-consistency metrics)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.det_data import make_tiny_vspw
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tree(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("vspw_tiny"))
+    make_tiny_vspw(root)
+    return root
+
+
+def _cfg(arch_dec):
+    from cvpr2021_vspw_implement_amd.config import cfg
+
+    c = cfg.clone()
+    c.MODEL.arch_encoder = "resnet50dilated"
+    c.MODEL.arch_decoder = arch_dec
+    c.MODEL.fc_dim = 2048
+    return c
+
+
+def test_clip_psp_train_checkpoint_eval(dev, tree, tmp_path):
+    import cvpr2021_vspw_implement_amd.test_clip2 as E
+    import cvpr2021_vspw_implement_amd.train_clip2 as T
+
+    save = str(tmp_path / "ck")
+    args = T.build_parser().parse_args([
+        "--method", "clip_psp", "--dataroot", tree, "--saveroot", save, "--batchsize", "3", "--cropsize", "40",
+        "--clip_num", "4", "--dilation2", "3,6,9", "--totalepoch", "2", "--ckpt_every", "2", "--lr", "0.01",
+        "--multi_scale", "true", "--workers", "0", "--gpus", "0"])
+    cfg = _cfg("ppm_deepsup_clip")
+    here = os.path.dirname(os.path.abspath(T.__file__))
+    args.cfg = os.path.join(here, "config", "vsp-resnet101dilated-ppm_deepsup_clip.yaml")
+    T.prepare(args, cfg)
+    cfg.MODEL.arch_encoder = "resnet50dilated"
+    lines = []
+    hist = T.main(cfg, [0], args)
+    losses = hist["train"]["loss"]
+    assert len(losses) == 2 and all(np.isfinite(losses))           # 3 videos / batch 3 = 1 iteration per epoch
+    sd = torch.load(os.path.join(save, "model_epoch_2.pth"), map_location="cpu")
+    assert all(k.startswith("module.") for k in sd) and "module.encoder.conv1.weight" in sd
+    assert os.path.exists(os.path.join(save, "opt_epoch_2.pth"))
+    # evaluation driver on the checkpoint it wrote
+    eargs = E.build_parser().parse_args([
+        "--method", "clip_psp", "--dataroot", tree, "--split", "test", "--load", os.path.join(save, "model_epoch_2.pth"),
+        "--batchsize", "1", "--clip_num", "4", "--dilation2", "3,6,9", "--vc_clip_num", "4", "--is_save", "true",
+        "--saveroot", str(tmp_path / "pred")])
+    eargs.max_distances = [10]
+    out = E.main(_cfg("ppm_deepsup_clip"), 0, eargs, log=lambda *a: lines.append(a))
+    assert 0.0 <= out["Acc"] <= 1.0 and 0.0 <= out["mIoU"] <= 1.0 and 0.0 <= out["video_mIoU"] <= 1.0
+    assert np.isnan(out["VC"]) or 0.0 <= out["VC"] <= 1.0
+    pngs = os.listdir(str(tmp_path / "pred" / "v_b"))
+    assert len(pngs) == 9  # one palette PNG per frame of the video
+
+
+def test_netwarp_train_step_with_hip_raft(dev, tree, tmp_path):
+    """netwarp: clip_num 2, RAFT (random init here) -> FlowCNN -> warps, through the training driver; frames are
+    padded to the 136-pixel crop so that RAFT's 1/8-resolution maps keep >= 16 rows."""
+    import cvpr2021_vspw_implement_amd.train_clip2 as T
+
+    args = T.build_parser().parse_args([
+        "--method", "netwarp", "--dataroot", tree, "--saveroot", str(tmp_path / "ck2"), "--batchsize", "1",
+        "--cropsize", "131", "--clip_num", "2", "--dilation_num", "0", "--totalepoch", "1", "--ckpt_every", "5",
+        "--lr", "0.01", "--raft_weights", "", "--validation", "false"])
+    cfg = _cfg("ppm_deepsup_clip")
+    here = os.path.dirname(os.path.abspath(T.__file__))
+    args.cfg = os.path.join(here, "config", "vsp-resnet101dilated-ppm_deepsup_clip.yaml")
+    T.prepare(args, cfg)
+    cfg.MODEL.arch_encoder = "resnet50dilated"
+    hist = T.main(cfg, [0], args)
+    assert len(hist["train"]["loss"]) == 3 and all(np.isfinite(hist["train"]["loss"]))

@@ -63,6 +63,12 @@ class ClipOCRNet(LrGroupsMixin, nn.Module):
         B = out_tmp.shape[0] // T
 
         all_frames = bool(self.args.clipocr_all)
+        if all_frames and T > 1:
+            # the reference cannot run this flag: spatial_ocr_head(out_tmp, context) pairs B*T frames of pixels with B
+            # object contexts and _ObjectAttentionBlock's view() rejects it (clip_ocr.py:136-137,
+            # spatial_ocr_block.py:263: "shape '[B*T, 256, -1]' is invalid for input of size ..."); same error class here
+            raise RuntimeError("clipocr_all with %d frames per clip: shape '[%d, 256, -1]' is invalid for the %d object "
+                               "contexts (the reference fails identically)" % (T, out_tmp.shape[0], B))
         x = out_tmp if all_frames else out_tmp[(T - 1) * B:]
         x = self.head(self.spatial_ocr_head(x, context))
         if segSize is not None:

@@ -114,6 +114,17 @@ def test_clip_heads(dev, kind):
     _check_train(fx, mod, loss, acc, tag)
 
 
+def test_clipocr_all_fails_like_the_reference(dev):
+    """--clipocr_all pairs B*T pixel frames with B object contexts; the reference's view() raises RuntimeError
+    (tools/make_golden.py could not produce a vector for it) and so does the mirror."""
+    mod = build("clip_ocr", "resnet50dilated", args={"clipocr_all": True}).to(dev)
+    inp = clip_inputs("r50_clip_ocr")
+    imgs = [_t(a, dev) for a in inp["train_imgs"]]
+    labs = [_t(a, dev) for a in inp["train_labs"]]
+    with pytest.raises(RuntimeError, match="invalid"):
+        mod({"img_data": imgs[-1], "seg_label": labs[-1], "clipimgs_data": imgs[:-1], "cliplabels_data": labs[:-1]})
+
+
 def test_clip_psp_against_live_oracle(dev):
     """Same comparison against the numpy oracle evaluated here (not a stored vector), on a different seed / shape
     (ragged 57x71 frames, T=2) than any fixture."""

@@ -217,6 +217,23 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const long long total = rows * cw;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
+    if (VEC && !mask && stride % cw == 0) {
+        // the grid stride is a multiple of the row length: this thread stays on one channel group, so the
+        // coefficients live in registers and the loop is pure streaming (no integer division per element)
+        const int ch = (int)(i % cw) * 4;
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + ch);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + ch);
+        for (; i < total; i += stride) {
+            f32x4 o = reinterpret_cast<const f32x4*>(x)[i] * sc + sh;
+            if (res) o += reinterpret_cast<const f32x4*>(res)[i];
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+            }
+            reinterpret_cast<f32x4*>(z)[i] = o;
+        }
+        return;
+    }
     for (; i < total; i += stride) {
         const long long r = i / cw;
         const int ch = (int)(i - r * cw) * W;
@@ -320,6 +337,51 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const long long total = rows * cw;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
+    if (VEC && !mask && stride % cw == 0) {
+        // fixed channel group per thread (see bn_apply_kernel): per-channel terms are hoisted; the per-element
+        // arithmetic is the same expression tree as the general path below (bit-identical results)
+        const int ch = (int)(i % cw) * 4;
+        f32x4 a = {1.f, 1.f, 1.f, 1.f}, is = a, mu = {0.f, 0.f, 0.f, 0.f}, mg = mu, mgx = mu;
+        if (dx) {
+            is = *reinterpret_cast<const f32x4*>(invstd + ch);
+            f32x4 gm = {1.f, 1.f, 1.f, 1.f};
+            if (gamma) gm = *reinterpret_cast<const f32x4*>(gamma + ch);
+            a = gm * is;
+            if (training) {
+                mu = *reinterpret_cast<const f32x4*>(mean + ch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    mg[e] = (float)(sums[ch + e] * inv_count);
+                    mgx[e] = (float)(sums[c + ch + e] * inv_count);
+                }
+            }
+        }
+        for (; i < total; i += stride) {
+            f32x4 g = reinterpret_cast<const f32x4*>(dz)[i];
+            if (relu) {
+                const f32x4 zv = reinterpret_cast<const f32x4*>(z)[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (!(zv[e] > 0.f)) g[e] = 0.f;
+            }
+            if (dres) reinterpret_cast<f32x4*>(dres)[i] = g;
+            if (dx) {
+                f32x4 o;
+                if (training) {
+                    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (xv[e] - mu[e]) * is[e];
+                        o[e] = a[e] * (g[e] - mg[e] - xh * mgx[e]);
+                    }
+                } else {
+                    o = a * g;
+                }
+                reinterpret_cast<f32x4*>(dx)[i] = o;
+            }
+        }
+        return;
+    }
     for (; i < total; i += stride) {
         const long long r = i / cw;
         const int ch = (int)(i - r * cw) * W;

@@ -104,11 +104,13 @@ __global__ __launch_bounds__(1024) void bn_finalize_partials_kernel(
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + tx;
     double s = 0, q = 0;
-    if (i < c)
-        for (int z = ty; z < tiles; z += 16) {
+    if (i < c) {
+#pragma unroll 8
+        for (int z = ty; z < tiles; z += 16) {  // unrolled: 16 independent loads in flight, same addition order
             s += (double)part[(size_t)z * 2 * c + i];
             q += (double)part[(size_t)z * 2 * c + c + i];
         }
+    }
     red[0][ty][tx] = s;
     red[1][ty][tx] = q;
     __syncthreads();
@@ -147,8 +149,10 @@ __global__ __launch_bounds__(1024) void reduce_partials_pg_kernel(const double* 
     const int col = blockIdx.x * 64 + tx;
     const int n = 2 * c;
     double a = 0;
-    if (col < n)
+    if (col < n) {
+#pragma unroll 8
         for (int z = ty; z < splits; z += 16) a += part[(size_t)z * n + col];
+    }
     red[ty][tx] = a;
     __syncthreads();
     if (ty == 0 && col < n) {

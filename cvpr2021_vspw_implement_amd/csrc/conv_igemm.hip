@@ -1071,7 +1071,24 @@ __global__ void weight_transpose_kernel(const float* __restrict__ in, float* __r
     }
 }
 
-// NCHW -> NHWC (and back) for the 3-channel images / class maps crossing the boundary.
+// NCHW -> NHWC for the images crossing the boundary.  One thread per pixel for small C (the 3-channel frames): plane
+// reads are coalesced across threads, the C outputs of a thread are contiguous; grid.y = image (no integer division).
+template <int C>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_small_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                 long long HW) {
+    const long long n = blockIdx.y;
+    const float* src = in + n * C * HW;
+    float* dst = out + n * C * HW;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += stride) {
+        float v[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) v[c] = src[c * HW + p];
+#pragma unroll
+        for (int c = 0; c < C; ++c) dst[p * C + c] = v[c];
+    }
+}
+
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, long long HW) {
     long long total = (long long)N * C * HW;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1265,6 +1282,11 @@ extern "C" int vspw_weight_transpose(const float* w, float* wT, int k, int taps,
 extern "C" int vspw_nchw_to_nhwc(const float* in, float* out, int n, int c, long long hw, void* stream) {
     if (!in || !out || n <= 0 || c <= 0 || hw <= 0) return VSPW_EINVAL;
     long long total = (long long)n * c * hw;
+    if (c == 3 && n <= 65535) {
+        hipLaunchKernelGGL(nchw_to_nhwc_small_kernel<3>, dim3(vspw_stream_grid(hw, 256), n), dim3(256), 0,
+                           vspw_stream(stream), in, out, hw);
+        return vspw_launch_status();
+    }
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream), in,
                        out, n, c, hw);
     return vspw_launch_status();

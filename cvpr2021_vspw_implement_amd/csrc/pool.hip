@@ -124,6 +124,67 @@ __global__ __launch_bounds__(AP_TX * AP_TY) void adaptive_avgpool_fwd_kernel(con
     }
 }
 
+// Fused forward of the PPM pyramid (all scales, ONE pass over x).  Stage 1: per (image, image row, 256-channel chunk)
+// the row's sum over every x-bin of every scale -> rowpart[img][row][slot][c] (slot = x-bin index, scales concatenated;
+// thread.y = scale, so the row is read once from HBM and re-read from L1 by the other scales).  Stage 2: sum the rows of
+// every y-bin and divide by the bin population.  n*h*(c/256) workgroups instead of (c/256)*s*s*n, which for s = 1..3 left
+// most of the chip idle.
+struct PoolFwdMulti {
+    float* y[4];
+    int s[4];
+    int slot0[4];  // first x-bin slot of scale k
+    int ns, nslots;
+};
+__global__ __launch_bounds__(256) void pyramid_pool_rows_kernel(const float* __restrict__ x, float* __restrict__ rowpart,
+                                                                PoolFwdMulti p, int h, int w, int c) {
+    const int tx = threadIdx.x, k = threadIdx.y;
+    const int row = blockIdx.y, img = blockIdx.z;
+    const int c0 = (blockIdx.x * 64 + tx) * 4;
+    if (k >= p.ns || c0 >= c) return;
+    const int s = p.s[k];
+    const float* src = x + (((size_t)img * h + row) * w) * c + c0;
+    float* dst = rowpart + (((size_t)img * h + row) * p.nslots + p.slot0[k]) * c + c0;
+    for (int bx = 0; bx < s; ++bx) {
+        const int x0 = bin_start(bx, w, s), x1 = bin_end(bx, w, s);
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int px = x0; px < x1; ++px) a += *reinterpret_cast<const f32x4*>(src + (size_t)px * c);
+        *reinterpret_cast<f32x4*>(dst + (size_t)bx * c) = a;
+    }
+}
+__global__ __launch_bounds__(256) void pyramid_pool_bins_kernel(const float* __restrict__ rowpart, PoolFwdMulti p, int n,
+                                                                int h, int w, int c) {
+    // one thread per (image, scale, by, bx, float4 of channels)
+    const int c4 = c >> 2;
+    int nbins = 0;
+    for (int k = 0; k < p.ns; ++k) nbins += p.s[k] * p.s[k];
+    const long long total = (long long)n * nbins * c4;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int ch = (int)(i % c4) * 4;
+        long long r = i / c4;
+        int bin = (int)(r % nbins);
+        const int img = (int)(r / nbins);
+        int k = 0;
+        while (bin >= p.s[k] * p.s[k]) {
+            bin -= p.s[k] * p.s[k];
+            ++k;
+        }
+        const int s = p.s[k];
+        const int by = bin / s, bx = bin - by * s;
+        const int y0 = bin_start(by, h, s), y1 = bin_end(by, h, s);
+        const int x0 = bin_start(bx, w, s), x1 = bin_end(bx, w, s);
+        const float* src = rowpart + (((size_t)img * h) * p.nslots + p.slot0[k] + bx) * c + ch;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int yy = y0; yy < y1; ++yy) a += *reinterpret_cast<const f32x4*>(src + (size_t)yy * p.nslots * c);
+        const float cnt = (float)((y1 - y0) * (x1 - x0));
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = a[e] / cnt;
+        *reinterpret_cast<f32x4*>(p.y[k] + (((size_t)img * s + by) * s + bx) * c + ch) = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
                                                                    int n, int h, int w, int c, int s, int accumulate) {
     const long long total = (long long)n * h * w * c;
@@ -265,6 +326,42 @@ extern "C" int vspw_adaptive_avgpool_fwd(const float* x, float* y, int n, int h,
     dim3 grid(vspw_cdiv(c, AP_TX * 4), s * s, n);
     hipLaunchKernelGGL(adaptive_avgpool_fwd_kernel, grid, dim3(AP_TX, AP_TY), 0, vspw_stream(stream), x, y, n, h, w, c,
                        s);
+    return vspw_launch_status();
+}
+
+extern "C" size_t vspw_pyramid_pool_fwd_workspace(const int* scales, int nscales, int n, int h, int c) {
+    if (!scales || nscales <= 0 || nscales > 4 || n <= 0 || h <= 0 || c <= 0) return 0;
+    long long slots = 0;
+    for (int k = 0; k < nscales; ++k) slots += scales[k];
+    return (size_t)n * h * slots * c * sizeof(float);
+}
+
+extern "C" int vspw_pyramid_pool_fwd(const float* x, const int* scales, int nscales, float* const* y, int n, int h,
+                                     int w, int c, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !scales || !y || nscales <= 0 || nscales > 4 || n <= 0 || n > 65535 || h <= 0 || h > 65535 || w <= 0 ||
+        c <= 0 || (c & 3))
+        return VSPW_EINVAL;
+    PoolFwdMulti p;
+    p.ns = nscales;
+    p.nslots = 0;
+    for (int k = 0; k < 4; ++k) {
+        p.y[k] = k < nscales ? y[k] : nullptr;
+        p.s[k] = k < nscales ? scales[k] : 1;
+        p.slot0[k] = p.nslots;
+        if (k < nscales) {
+            if (!y[k] || scales[k] <= 0) return VSPW_EINVAL;
+            p.nslots += scales[k];
+        }
+    }
+    if (!ws || ws_bytes < (size_t)n * h * p.nslots * c * sizeof(float)) return VSPW_EINVAL;
+    float* rowpart = reinterpret_cast<float*>(ws);
+    hipStream_t st = vspw_stream(stream);
+    hipLaunchKernelGGL(pyramid_pool_rows_kernel, dim3(vspw_cdiv(c, 256), h, n), dim3(64, 4), 0, st, x, rowpart, p, h, w,
+                       c);
+    long long nbins = 0;
+    for (int k = 0; k < nscales; ++k) nbins += (long long)scales[k] * scales[k];
+    hipLaunchKernelGGL(pyramid_pool_bins_kernel, dim3(vspw_stream_grid((long long)n * nbins * (c / 4), 256)), dim3(256), 0,
+                       st, rowpart, p, n, h, w, c);
     return vspw_launch_status();
 }
 

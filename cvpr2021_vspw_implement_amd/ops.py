@@ -462,9 +462,17 @@ class PyramidPoolFn(torch.autograd.Function):
             wts = wts.contiguous()
             if tuple(wts.shape) != (B, T):
                 raise RuntimeError("pyramid_pool: temporal weights must be [B, T] = [%d, %d]" % (B, T))
-        for s in scales:
-            pooled = empty_nhwc(n, c, s, s, x.device)
-            _C.call("vspw_adaptive_avgpool_fwd", _p(x), _p(pooled), n, h, w, c, s, st)
+        pooled_all = [empty_nhwc(n, c, s, s, x.device) for s in scales]
+        fused = c % 4 == 0 and 0 < len(scales) <= 4
+        if fused:  # every scale from one pass over x
+            svec = (ctypes.c_int * len(scales))(*scales)
+            ptrs = (ctypes.c_void_p * len(scales))(*[t.data_ptr() for t in pooled_all])
+            nbytes = _C.query("vspw_pyramid_pool_fwd_workspace", svec, len(scales), n, h, c)
+            ws = _ws(nbytes, x.device)
+            _C.call("vspw_pyramid_pool_fwd", _p(x), svec, len(scales), ptrs, n, h, w, c, _p(ws), nbytes, st)
+        for s, pooled in zip(scales, pooled_all):
+            if not fused:
+                _C.call("vspw_adaptive_avgpool_fwd", _p(x), _p(pooled), n, h, w, c, s, st)
             if T > 1:
                 blended = empty_nhwc(B, c, s, s, x.device)
                 _C.call("vspw_temporal_mean_fwd", _p(pooled), _p(wts), _p(blended), T, B, s * s * c, st)

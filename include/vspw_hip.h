@@ -118,6 +118,11 @@ int vspw_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float* dx, int n,
                           int ow, void* stream);
 /* nn.AdaptiveAvgPool2d(s) (models/clip_psp.py:85-87,160-166, models/models.py:947,972): y [n][s][s][c]. */
 int vspw_adaptive_avgpool_fwd(const float* x, float* y, int n, int h, int w, int c, int s, void* stream);
+/* All pyramid scales in one pass over x (c % 4 == 0): y[k] [n][s_k][s_k][c].  scales / y are HOST arrays of nscales
+ * (<= 4) entries; ws holds the per-row partial sums (vspw_pyramid_pool_fwd_workspace bytes). */
+size_t vspw_pyramid_pool_fwd_workspace(const int* scales, int nscales, int n, int h, int c);
+int vspw_pyramid_pool_fwd(const float* x, const int* scales, int nscales, float* const* y, int n, int h, int w, int c,
+                          void* ws, size_t ws_bytes, void* stream);
 /* dx (+)= adjoint; accumulate != 0 adds into dx. */
 int vspw_adaptive_avgpool_bwd(const float* dy, float* dx, int n, int h, int w, int c, int s, int accumulate,
                               void* stream);

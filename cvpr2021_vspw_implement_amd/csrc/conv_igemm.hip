@@ -32,6 +32,7 @@ struct IgemmNT {
     const float* bias;  // [nout] or nullptr
     float* dst;         // [m][ldd]
     float* stat_part;   // optional [tiles_m][2][nout] per-tile column sum / sumsq (fused BN stats)
+    const float* addend;  // optional [m][ldd], added in the epilogue (skip-connection gradient folded into the dgrad)
     int nb, h, w, c;    // src dims
     int oh, ow;         // pixel grid of the GEMM M dimension
     int kh, kw, stride, pad, padw, dil;  // pad: rows (H), padw: columns (W)
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
                 const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (cok && row < p.m) {
                     float v = nt_act(acc[i][j][r] + bv, p.act);
+                    if (p.addend != nullptr) v += p.addend[(size_t)row * p.ldd + col];
                     p.dst[(size_t)row * p.ldd + col] = v;
                     csum[j] += v;
                     csq[j] += v * v;
@@ -479,7 +481,21 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
     if ((m0 + TM <= p.m) & (n0 + TN <= p.nout) & (p.act == 0)) {
         // interior tile (uniform test): unguarded stores at `uniform base + constant per-lane byte offset`
         char* dbase = reinterpret_cast<char*>(p.dst + (size_t)m0 * p.ldd + n0);
+        const char* abase = p.addend ? reinterpret_cast<const char*>(p.addend + (size_t)m0 * p.ldd + n0) : nullptr;
         const unsigned lane_off = (unsigned)((wm * 32 * WM + 4 * lh) * p.ldd + wn * 32 * WN + l31) * 4u;
+        if (abase != nullptr) {
+            // all addend loads first, with no store in between (dst and addend are not provably distinct to the
+            // compiler, so loads interleaved with the stores below would each wait out their full latency)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const size_t uoff = ((size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldd + j * 32) * 4;
+                        acc[i][j][r] += *reinterpret_cast<const float*>(abase + uoff + lane_off);
+                    }
+        }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             csum[j] = 0.f;
@@ -512,6 +528,7 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
                     const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (cok && row < p.m) {
                         float v = nt_act(acc[i][j][r] + bv, p.act);
+                        if (p.addend != nullptr) v += p.addend[(size_t)row * p.ldd + col];
                         p.dst[(size_t)row * p.ldd + col] = v;
                         csum[j] += v;
                         csq[j] += v * v;
@@ -1112,7 +1129,7 @@ static int conv_geometry_ok(const vspw_conv_desc* d) {
 }
 
 static bool fill_fwd_params(const vspw_conv_desc* d, IgemmNT& p) {
-    p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr;
+    p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr; p.addend = nullptr;
     p.nb = d->n; p.h = d->h; p.w = d->w; p.c = d->c;
     p.oh = d->oh; p.ow = d->ow;
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;
@@ -1160,11 +1177,25 @@ extern "C" int vspw_conv2d_fwd_ex(const vspw_conv_desc* d, const float* x, long 
     return launch_igemm_nt(p, vspw_stream(stream));
 }
 
+static int conv2d_bwd_data_impl(const vspw_conv_desc* d, const float* dy, const float* wT, const float* addend,
+                                float* dx, void* stream);
+
 extern "C" int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, const float* wT, float* dx,
                                     void* stream) {
+    return conv2d_bwd_data_impl(d, dy, wT, nullptr, dx, stream);
+}
+
+extern "C" int vspw_conv2d_bwd_data_acc(const vspw_conv_desc* d, const float* dy, const float* wT,
+                                        const float* addend, float* dx, void* stream) {
+    if (!addend) return VSPW_EINVAL;
+    return conv2d_bwd_data_impl(d, dy, wT, addend, dx, stream);
+}
+
+static int conv2d_bwd_data_impl(const vspw_conv_desc* d, const float* dy, const float* wT, const float* addend,
+                                float* dx, void* stream) {
     if (!conv_geometry_ok(d) || !dy || !wT || !dx) return VSPW_EINVAL;
     IgemmNT p;
-    p.src = dy; p.wt = wT; p.bias = nullptr; p.dst = dx; p.stat_part = nullptr;
+    p.src = dy; p.wt = wT; p.bias = nullptr; p.dst = dx; p.stat_part = nullptr; p.addend = addend;
     p.nb = d->n; p.h = d->oh; p.w = d->ow; p.c = d->k;   // gather over dY
     p.oh = d->h; p.ow = d->w;                              // rows are input pixels
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;

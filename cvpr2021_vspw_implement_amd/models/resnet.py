@@ -6,6 +6,7 @@ executed as fused conv+BN(+residual)+ReLU kernel chains instead of separate ATen
 """
 import math
 
+import torch
 import torch.nn as nn
 
 from .. import nn as vnn
@@ -64,9 +65,15 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+        # the skip connection is taken from conv1's node (skip_out): in backward its gradient is added in conv1's
+        # data-gradient epilogue instead of by a separate accumulation pass over the block input
+        skip = x
+        if x.requires_grad and torch.is_grad_enabled():
+            out, skip = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True, skip_out=True)
+        else:
+            out = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         out = vnn.conv_bn_act(out, self.conv2, self.bn2, relu=True)
-        return vnn.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=_residual_branch(self, x))
+        return vnn.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=_residual_branch(self, skip))
 
 
 class ResNet(nn.Module):

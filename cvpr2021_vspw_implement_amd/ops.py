@@ -136,13 +136,20 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False):
     return y, part, d
 
 
-def conv2d_backward_data(dy, w, d):
+def conv2d_backward_data(dy, w, d, addend=None):
+    """dx = conv_backward_input(dy, w) [+ addend, folded into the GEMM epilogue]."""
     k, c, kh, kw = w.shape
     wT = torch.empty((c, kh, kw, k), device=w.device, dtype=torch.float32)
     _C.call("vspw_weight_transpose", _p(w), _p(wT), k, kh * kw, c, _stream())
     dx = empty_nhwc(d.n, d.c, d.h, d.w, dy.device)
     with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "dgrad")):
-        _C.call("vspw_conv2d_bwd_data", ctypes.byref(d), _p(dy), _p(wT), _p(dx), _stream())
+        if addend is None:
+            _C.call("vspw_conv2d_bwd_data", ctypes.byref(d), _p(dy), _p(wT), _p(dx), _stream())
+        else:
+            addend = to_nhwc(addend)
+            if tuple(addend.shape) != tuple(dx.shape):
+                raise RuntimeError("conv2d_backward_data: addend %s vs dx %s" % (tuple(addend.shape), tuple(dx.shape)))
+            _C.call("vspw_conv2d_bwd_data_acc", ctypes.byref(d), _p(dy), _p(wT), _p(addend), _p(dx), _stream())
     return dx
 
 
@@ -317,7 +324,7 @@ class ConvBNActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, cbias, gamma, beta, running_mean, running_var, residual, mask, stride, pad, dil, training,
-                momentum, eps, relu):
+                momentum, eps, relu, skip_out=False):
         _require_gpu(x, "conv_bn_act")
         x = to_nhwc(x)
         fuse_stats = training
@@ -368,10 +375,15 @@ class ConvBNActFn(torch.autograd.Function):
         ctx.has_res = residual is not None
         ctx.has_cbias = cbias is not None
         ctx.save_for_backward(x, w, y, z if relu else None, gamma, coef, mask)
+        ctx.skip_out = bool(skip_out)
+        if skip_out:
+            # second output = the input itself (autograd turns it into a view with this node as grad_fn): the block's
+            # skip connection is routed through here so that its gradient is added in this conv's dgrad epilogue
+            return z, x
         return z
 
     @staticmethod
-    def backward(ctx, dz):
+    def backward(ctx, dz, dskip=None):
         x, w, y, z, gamma, coef, mask = ctx.saved_tensors
         d = ctx.d
         dz = to_nhwc(dz)
@@ -400,18 +412,20 @@ class ConvBNActFn(torch.autograd.Function):
             w = w.contiguous(memory_format=torch.channels_last)
         dx = dw = dcb = None
         if ctx.needs_input_grad[0]:
-            dx = conv2d_backward_data(dy, w, d)
+            dx = conv2d_backward_data(dy, w, d, addend=dskip if ctx.skip_out else None)
         if ctx.needs_input_grad[1]:
             dw = conv2d_backward_weight(dy, x, d)
         if ctx.has_cbias and ctx.needs_input_grad[2]:
             dcb = colsum(rows, c, dy)
-        return (dx, dw, dcb, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None)
+        return (dx, dw, dcb, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None)
 
 
 def conv_bn_act(x, w, cbias, gamma, beta, running_mean, running_var, residual=None, mask=None, stride=1, pad=0,
-                dil=1, training=True, momentum=0.1, eps=1e-5, relu=True):
+                dil=1, training=True, momentum=0.1, eps=1e-5, relu=True, skip_out=False):
+    """skip_out: also return the input as a second output (see ConvBNActFn.forward) - use THAT tensor for the skip
+    connection of a residual block and its gradient is folded into this convolution's data-gradient epilogue."""
     return ConvBNActFn.apply(x, w, cbias, gamma, beta, running_mean, running_var, residual, mask, stride, pad, dil,
-                             training, momentum, eps, relu)
+                             training, momentum, eps, relu, skip_out)
 
 
 # --------------------------------------------------------------------------------------------------- pooling

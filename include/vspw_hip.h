@@ -58,6 +58,10 @@ int vspw_conv2d_fwd_ex(const vspw_conv_desc* d, const float* x, long long ldx, c
                        int act, float* y, long long ldy, void* stream);
 /* dx = conv2d_backward_input(dy, w).  wT is the [c][kh][kw][k] copy of w made by vspw_weight_transpose. */
 int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, const float* wT, float* dx, void* stream);
+/* dx = conv2d_backward_input(dy, w) + addend: the gradient arriving over the skip connection (models/resnet.py:75-90:
+ * `out += residual`) is added in the GEMM epilogue instead of by a separate pass.  addend has dx's shape/layout. */
+int vspw_conv2d_bwd_data_acc(const vspw_conv_desc* d, const float* dy, const float* wT, const float* addend, float* dx,
+                             void* stream);
 /* dw [k][kh][kw][c] = conv2d_backward_weight(dy, x); split-K over pixels, deterministic reduction. */
 size_t vspw_conv2d_bwd_weight_workspace(const vspw_conv_desc* d);
 int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, const float* x, float* dw, void* ws,

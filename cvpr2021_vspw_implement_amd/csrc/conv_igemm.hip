@@ -327,7 +327,10 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
     const int img0 = m0 / ohw;
     const char* src0 = reinterpret_cast<const char*>(p.src + (size_t)img0 * p.h * p.w * p.lds);
     const char* wt0 = reinterpret_cast<const char*>(p.wt + (size_t)n0 * p.kdim);
-    const bool pointwise = (p.kh * p.kw == 1) & (p.stride == 1) & (p.pad == 0) & (p.padw == 0);  // src pixel == out pixel
+    // MODE 2 = pointwise at compile time (1x1, stride 1, no padding: source pixel == output pixel, every tap in the
+    // image): no tap state, no in-image bits, no selects - the K loop is a plain GEMM loop
+    constexpr bool PW = MODE == 2;
+    const bool pointwise = PW || ((p.kh * p.kw == 1) & (p.stride == 1) & (p.pad == 0) & (p.padw == 0));
 
     int a_base[RA], a_by[RA], a_bx[RA];
     unsigned a_voff[RA];    // byte offset (from src0) of this row's source pixel for the current tap, + lcol
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
         kb += BK;
         cb += BK;
         more = kb < p.kdim;
-        if (more && cb == p.c) {
+        if (!PW && more && cb == p.c) {
             cb = 0;
             if (++kx == p.kw) {
                 kx = 0;
@@ -409,7 +412,8 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
     auto store_tile = [&](float* Ad, float* Bd) {
 #pragma unroll
         for (int i = 0; i < RA; ++i)
-            *reinterpret_cast<f32x4*>(&Ad[(lrow + 32 * i) * LDA + lcol]) = ((ok_regs >> i) & 1u) ? ra[i] : zero4;
+            *reinterpret_cast<f32x4*>(&Ad[(lrow + 32 * i) * LDA + lcol]) =
+                (PW || ((ok_regs >> i) & 1u)) ? ra[i] : zero4;
 #pragma unroll
         for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bd[(lrow + 32 * i) * LDA + lcol]) = rb[i];
     };
@@ -638,7 +642,10 @@ static int launch_igemm_nt(const IgemmNT& p, hipStream_t st) {
     bool v2;
     const int cfg = nt_decide(p, v2);
     if (v2) {
-        if (p.mode == 0)
+        const bool pw = p.kh * p.kw == 1 && p.stride == 1 && p.pad == 0 && p.padw == 0;
+        if (pw)
+            launch_nt_v2<2>(p, cfg, st);  // forward and data gradient of a pointwise conv are the same plain GEMM
+        else if (p.mode == 0)
             launch_nt_v2<0>(p, cfg, st);
         else
             launch_nt_v2<1>(p, cfg, st);

@@ -75,6 +75,11 @@ def load(check_symbols: bool = False):
             "libvspw_hip.so is missing (%s). Build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback for the hot path." % LIB_PATH
         )
+    # torch bundles its own HIP/HSA runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).  It must be in the
+    # process BEFORE this library is opened, so that the library's libamdhip64 dependency resolves to that copy: with
+    # the opposite order two HIP runtimes coexist and every launch here fails with hipErrorNoDevice.
+    import torch  # noqa: F401
+
     lib = ctypes.CDLL(LIB_PATH)
     decls = parse_header()
     missing = []
@@ -99,7 +104,15 @@ _ERR = {-1: "VSPW_EINVAL (bad argument / geometry / workspace)", -2: "VSPW_ELAUN
 
 def check(rc: int, what: str):
     if rc != 0:
-        raise RuntimeError("%s failed: %s" % (what, _ERR.get(rc, str(rc))))
+        detail = ""
+        if rc == -2 and _lib is not None:
+            try:
+                fn = _lib.vspw_last_hip_error_string
+                fn.restype = ctypes.c_char_p
+                detail = " [hipError %d: %s]" % (_lib.vspw_last_hip_error(), fn().decode())
+            except Exception:  # pragma: no cover - diagnostics only
+                pass
+        raise RuntimeError("%s failed: %s%s" % (what, _ERR.get(rc, str(rc)), detail))
 
 
 def call(name: str, *args):

@@ -10,8 +10,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define VSPW_WAVE 64
 
+extern "C" int vspw_hip_error_code;  // last non-success hipError_t seen by vspw_launch_status (misc.hip)
 static inline int vspw_launch_status() {
     hipError_t e = hipGetLastError();
+    if (e != hipSuccess) vspw_hip_error_code = (int)e;
     return e == hipSuccess ? VSPW_OK : VSPW_ELAUNCH;
 }
 

@@ -4,6 +4,12 @@
 
 extern "C" int vspw_abi_version(void) { return VSPW_ABI_VERSION; }
 
+int vspw_hip_error_code = 0;
+extern "C" int vspw_last_hip_error(void) { return vspw_hip_error_code; }
+extern "C" const char* vspw_last_hip_error_string(void) {
+    return hipGetErrorString(static_cast<hipError_t>(vspw_hip_error_code));
+}
+
 __global__ void transpose_batched_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
     __shared__ float tile[32][33];
     const size_t base = (size_t)blockIdx.z * R * C;

@@ -31,6 +31,8 @@ extern "C" {
 
 #define VSPW_ABI_VERSION 1
 int vspw_abi_version(void);
+/* The hipError_t behind the most recent VSPW_ELAUNCH (0 if none) - for error messages. */
+int vspw_last_hip_error(void);
 
 /* ---------------------------------------------------------------- convolution (conv_igemm.hip) ---- */
 /* Geometry of one nn.Conv2d call: x [n,h,w,c] -> y [n,oh,ow,k], square stride/pad/dilation.

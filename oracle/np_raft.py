@@ -48,7 +48,8 @@ def relu(x):
 
 
 def sigmoid(x):
-    return (1.0 / (1.0 + np.exp(-x))).astype(x.dtype)
+    with np.errstate(over="ignore"):  # exp overflow -> inf -> 1/(1+inf) = 0, the correct limit
+        return (1.0 / (1.0 + np.exp(-x))).astype(x.dtype)
 
 
 def _norm(x, sd, prefix, kind):

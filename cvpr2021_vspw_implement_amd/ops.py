@@ -73,10 +73,14 @@ def _conv_desc(x, k, kh, kw, stride, pad, dil):
 _ktimer = {"on": False, "records": []}
 
 
-def kernel_timer(enable):
+def kernel_timer(enable, reset=True):
     _ktimer["on"] = bool(enable)
-    if enable:
+    if enable and reset:
         _ktimer["records"] = []
+
+
+def kernel_timer_reset():
+    _ktimer["records"] = []
 
 
 def kernel_timer_records():

@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
 //   * zeroing of out-of-image taps is a select applied when the registers are written to LDS (one K-tile later), so
 //     no vmcnt wait is forced near the load; rows >= M and columns >= Cout read clamped (valid) addresses and are
 //     simply never stored.
-// MODE 0: forward gather (any stride);  MODE 1: data-gradient gather, stride 1.
+// MODE 0: forward gather (any stride);  MODE 1: data-gradient gather (any stride);  MODE 2: pointwise.
 // WGM = waves along M (2: 2x2 waves, 1: 1x4 waves); workgroup tile = (32*WM*WGM) x (32*WN*(4/WGM)).
 template <int WGM, int WM, int WN, int MODE, int NBUF>
 __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
@@ -366,9 +366,17 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
         a_okbits = 0;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int sy = a_by[i] + sgn * ky;
-            const int sx = a_bx[i] + sgn * kx;
-            const bool ok = ((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w);
+            int sy = a_by[i] + sgn * ky;
+            int sx = a_bx[i] + sgn * kx;
+            bool ok = true;
+            if (MODE == 1 && p.stride != 1) {
+                // strided data gradient: tap (ky, kx) reaches this input pixel only from output pixel
+                // ((iy + pad - ky*dil) / stride, ...) when the division is exact (uniform branch, taken per tap)
+                ok = (sy >= 0) & (sx >= 0) & (sy % p.stride == 0) & (sx % p.stride == 0);
+                sy = sy >= 0 ? sy / p.stride : -1;
+                sx = sx >= 0 ? sx / p.stride : -1;
+            }
+            ok = ok & ((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w);
             const int syc = min(max(sy, 0), p.h - 1), sxc = min(max(sx, 0), p.w - 1);
             a_voff[i] = (unsigned)(((a_base[i] + syc) * p.w + sxc) * p.lds + lcol) * 4u;
             a_okbits |= ok ? (1u << i) : 0u;
@@ -633,7 +641,7 @@ static int nt_decide(const IgemmNT& p, bool& v2) {
     const long long img_elems = (long long)p.h * p.w * p.lds;
     const long long span = (128 / ((long long)p.oh * p.ow) + 2) * img_elems;
     v2 = p.vec && p.c % BK == 0 && span < (1LL << 30) && (long long)p.kdim < (1LL << 22) &&
-         (p.mode == 0 || p.stride == 1);
+         true;  // forward (any stride) and data gradient (any stride: inexact taps are masked per tap)
     if (!v2 && cfg == 31) cfg = 12;  // the generic kernel has no 96-row instantiation
     return cfg;
 }

@@ -427,12 +427,30 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
     };
 
     f32x16 acc[WM][WN];
+    // interior tile (uniform): unguarded epilogue.  With a skip-connection addend the accumulators START from it
+    // (C = addend, then C += A*B): its loads are issued here, in the shadow of the first operand tiles, instead of in
+    // the epilogue where nothing hides their latency.
+    const bool interior = (m0 + TM <= p.m) & (n0 + TN <= p.nout) & (p.act == 0);
+    const unsigned lane_off = (unsigned)((wm * 32 * WM + 4 * lh) * p.ldd + wn * 32 * WN + l31) * 4u;
+    if (p.addend != nullptr && interior) {
+        const char* abase = reinterpret_cast<const char*>(p.addend + (size_t)m0 * p.ldd + n0);
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
+            for (int j = 0; j < WN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const size_t uoff = ((size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldd + j * 32) * 4;
+                    acc[i][j][r] = *reinterpret_cast<const float*>(abase + uoff + lane_off);
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
 
     const int nk = p.kdim / BK;
     // prologue: tile 0 -> LDS[0]; tile 1 -> registers
@@ -490,24 +508,9 @@ __global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
     }
 
     float csum[WN], csq[WN];
-    if ((m0 + TM <= p.m) & (n0 + TN <= p.nout) & (p.act == 0)) {
-        // interior tile (uniform test): unguarded stores at `uniform base + constant per-lane byte offset`
+    if (interior) {
+        // unguarded stores at `uniform base + constant per-lane byte offset` (any addend is already in acc)
         char* dbase = reinterpret_cast<char*>(p.dst + (size_t)m0 * p.ldd + n0);
-        const char* abase = p.addend ? reinterpret_cast<const char*>(p.addend + (size_t)m0 * p.ldd + n0) : nullptr;
-        const unsigned lane_off = (unsigned)((wm * 32 * WM + 4 * lh) * p.ldd + wn * 32 * WN + l31) * 4u;
-        if (abase != nullptr) {
-            // all addend loads first, with no store in between (dst and addend are not provably distinct to the
-            // compiler, so loads interleaved with the stores below would each wait out their full latency)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const size_t uoff = ((size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldd + j * 32) * 4;
-                        acc[i][j][r] += *reinterpret_cast<const float*>(abase + uoff + lane_off);
-                    }
-        }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             csum[j] = 0.f;

@@ -37,9 +37,10 @@ def _data():
     return img, lab
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
+    local = rank if backend == "nccl" else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      LOCAL_RANK=str(local), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
@@ -47,9 +48,9 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, os.path.dirname(here))
     from cvpr2021_vspw_implement_amd import distributed as vdist
 
-    vdist.init_from_env(backend="gloo")
-    dev = torch.device("cuda:0")
-    torch.cuda.set_device(0)
+    vdist.init_from_env(backend=backend)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(local)
     mod = _build(dev)
     wrapped = vdist.DataParallelOverRCCL(mod, bucket_mb=4.0, sync_bn=True)
     img, lab = _data()
@@ -67,10 +68,20 @@ def _worker(rank, world, port, q):
 
 
 def test_two_ranks_equal_one_full_batch(dev):
+    _two_ranks(dev, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one device per rank (single-GPU box)")
+def test_two_ranks_rccl_equal_one_full_batch(dev):
+    """Same check over RCCL / xGMI with one process per GPU - runs wherever two devices are visible."""
+    _two_ranks(dev, "nccl")
+
+
+def _two_ranks(dev, backend):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in range(2))

@@ -72,6 +72,10 @@ __global__ __launch_bounds__(256) void gemm_nt(const float* __restrict__ A, cons
         const int cur = (NBUF == 2) ? (kt & 1) : 0;
         if (NBUF == 1) {
             if (FLAGS & 2) store_tile(As[0], Bs[0]);
+            if ((FLAGS & 64) && (FLAGS & 1)) {  // early issue: right after the registers are free
+                int k = (kt + 1) * BK;
+                load_tile(k < K ? k : 0);
+            }
             if (FLAGS & 4) __syncthreads();
         }
         const float* Ac = As[cur];
@@ -95,8 +99,8 @@ __global__ __launch_bounds__(256) void gemm_nt(const float* __restrict__ A, cons
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
             if (kc == 0) {
                 if (NBUF == 2 && (FLAGS & 2)) store_tile(As[(NBUF - 1) & (cur ^ 1)], Bs[(NBUF - 1) & (cur ^ 1)]);
-                if (FLAGS & 1) {
-                    int k = (kt + 2) * BK;
+                if ((FLAGS & 1) && !((FLAGS & 64) && NBUF == 1)) {
+                    int k = (kt + (NBUF == 2 ? 2 : 1)) * BK;
                     load_tile(k < K ? k : 0);
                 }
             }
@@ -158,6 +162,9 @@ int main() {
     run<15 + 32, 1>("full + zero select at ds_write", A, B, C, M, N, K);
     run<15 + 48, 1>("full + xcd remap + select", A, B, C, M, N, K);
     run<15 + 16, 2>("full + xcd remap", A, B, C, M, N, K);
+    run<15 + 64, 1>("full, loads issued at the top", A, B, C, M, N, K);
+    run<15, 1>("full (repeat)", A, B, C, M, N, K);
+    run<15 + 64, 1>("full, loads issued at the top (repeat)", A, B, C, M, N, K);
     // the library's conv kernel on the same GEMM (1x1 conv, n=1, 128x128 pixels, 4096 -> 4096 channels)
     void* lib = dlopen("cvpr2021_vspw_implement_amd/lib/libvspw_hip.so", RTLD_NOW);
     if (lib) {

@@ -299,8 +299,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
 //     simply never stored.
 // MODE 0: forward gather (any stride);  MODE 1: data-gradient gather (any stride);  MODE 2: pointwise.
 // WGM = waves along M (2: 2x2 waves, 1: 1x4 waves); workgroup tile = (32*WM*WGM) x (32*WN*(4/WGM)).
+// Register budget: tiles with <= 48 accumulator registers per lane are compiled for 4 waves per SIMD (<= 128 unified
+// registers, accumulators in VGPRs, no spills - checked with -Rpass-analysis=kernel-resource-usage); the 128x128 tile
+// (64 accumulators) would spill under that cap and stays at 3.  Measured: +1 % on the 3x3 shapes; the pointwise
+// shapes lose 4-5 % with the fourth wave (more L2 pressure per CU), so MODE 2 stays at 3 as well.
 template <int WGM, int WM, int WN, int MODE, int NBUF>
-__global__ __launch_bounds__(256) void igemm_nt_v2_kernel(IgemmNT p) {
+__global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 : (NBUF == 1 ? 3 : 2)) void igemm_nt_v2_kernel(
+    IgemmNT p) {
     constexpr int WGN = 4 / WGM;
     constexpr int TM = 32 * WM * WGM, TN = 32 * WN * WGN;
     constexpr int RA = TM / 32, RB = TN / 32;

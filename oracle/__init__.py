@@ -1,3 +1,3 @@
 """ORACLE — CPU restatement of the reference's hot-path arithmetic.  TEST INFRASTRUCTURE ONLY: imported by tests/,
 __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by cvpr2021_vspw_implement_amd/.
-Parity status: PINNED against tests/golden/*.npz, generated from the reference itself by tools/make_golden.py."""
+Parity status: PINNED against tests/golden/*.npz, generated from the reference itself by tests/golden/make_golden.py."""

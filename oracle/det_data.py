@@ -1,5 +1,5 @@
 """ORACLE / test infrastructure: a tiny deterministic VSPW-format tree (dataset2.py:866-884 layout) and a numpy
-restatement of what the reference's datasets do to a decoded frame (dataset2.py:921-977,1015-1035).  tools/make_golden.py
+restatement of what the reference's datasets do to a decoded frame (dataset2.py:921-977,1015-1035).  tests/golden/make_golden.py
 writes the tree, runs the REFERENCE dataset classes on it and stores their outputs; the tests rebuild the same tree
 (same PIL build => same bytes) and compare the HIP input pipeline with those outputs."""
 import os

@@ -1,7 +1,7 @@
 """ORACLE / test infrastructure: deterministic, name-keyed parameter values.
 
 The golden fixtures were produced by loading exactly these values into the REFERENCE modules
-(tools/make_golden.py); the GPU tests load the same values into the HIP-backed modules, and the numpy oracle reads
+(tests/golden/make_golden.py); the GPU tests load the same values into the HIP-backed modules, and the numpy oracle reads
 them directly — so no weights need to be stored or shipped.  numpy's legacy RandomState stream is stable across
 versions; values depend only on (state_dict key, shape, seed).
 """

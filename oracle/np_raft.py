@@ -2,7 +2,7 @@
 RAFT_core/raft.py:75-127 as NetWarp calls it (models/netwarp.py:170-176: eval mode, iters=20, test_mode=True).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.  Pinned by
-tests/golden/raft_basic.npz (tools/make_golden.py imports the reference's RAFT with oracle/det_init.py weights).
+tests/golden/raft_basic.npz (tests/golden/make_golden.py imports the reference's RAFT with oracle/det_init.py weights).
 Layout: the reference's NCHW; `sd` is a {state_dict key: ndarray} mapping with the reference's key names.
 """
 import numpy as np

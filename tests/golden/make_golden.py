@@ -4,7 +4,7 @@ seeded cases.  Runs only in the build container (the GPU box has no /root/refere
 arrays only: inputs are regenerated from seeds (oracle/det_init.py), weights likewise, so a fixture holds the expected
 outputs (logits, probabilities, arg-max, loss, accuracy, gradients / gradient norms).
 
-    python tools/make_golden.py            # (re)writes every fixture
+    python tests/golden/make_golden.py            # (re)writes every fixture
 
 Nothing from the reference is copied: it is imported, executed and discarded.
 """
@@ -14,7 +14,7 @@ import types
 
 os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
 sys.dont_write_bytecode = True
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
 sys.path.insert(0, ROOT)
 

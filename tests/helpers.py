@@ -46,7 +46,7 @@ def build(kind, arch, decoder=None, fc_dim=2048, **kw):
 
 def det_numpy_state(module, skip_prefix=(), fx=None):
     """Name-keyed deterministic weights; BatchNorm running statistics come from the fixture when it stores the
-    calibrated ones ("bnstat:<key>", see tools/make_golden.py:calibrate_bn)."""
+    calibrated ones ("bnstat:<key>", see tests/golden/make_golden.py:calibrate_bn)."""
     sd = {k: det_tensor(k, tuple(v.shape)) for k, v in module.state_dict().items()
           if not any(k.startswith(p) for p in skip_prefix)}
     if fx is not None:
@@ -128,7 +128,7 @@ def logit_tol(fx, floor=1e-3):
 
 
 def calibrate_bn_hip(module, run_train_forward):
-    """Same recipe as tools/make_golden.py:calibrate_bn, on the HIP modules: one training-mode forward with momentum 1
+    """Same recipe as tests/golden/make_golden.py:calibrate_bn, on the HIP modules: one training-mode forward with momentum 1
     sets every running statistic to the batch statistic, so that eval mode is meaningful with random weights."""
     bns = [m for m in module.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
     for m in bns:
@@ -142,7 +142,7 @@ def calibrate_bn_hip(module, run_train_forward):
 
 # ------------------------------------------------------------------------------------------------------ RAFT
 def raft_images(tag, shape):
-    """Same two frames as tools/make_golden.py:raft_images."""
+    """Same two frames as tests/golden/make_golden.py:raft_images."""
     a = np.clip(det_input(tag + ":img1", shape) * 60.0 + 120.0, 0.0, 255.0).astype(np.float32)
     b = np.roll(a, (2, -3), axis=(2, 3)) + det_input(tag + ":noise", shape) * 4.0
     return a, np.clip(b, 0.0, 255.0).astype(np.float32)

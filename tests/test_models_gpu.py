@@ -116,7 +116,7 @@ def test_clip_heads(dev, kind):
 
 def test_clipocr_all_fails_like_the_reference(dev):
     """--clipocr_all pairs B*T pixel frames with B object contexts; the reference's view() raises RuntimeError
-    (tools/make_golden.py could not produce a vector for it) and so does the mirror."""
+    (tests/golden/make_golden.py could not produce a vector for it) and so does the mirror."""
     mod = build("clip_ocr", "resnet50dilated", args={"clipocr_all": True}).to(dev)
     inp = clip_inputs("r50_clip_ocr")
     imgs = [_t(a, dev) for a in inp["train_imgs"]]

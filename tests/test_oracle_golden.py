@@ -1,5 +1,5 @@
 """Pins the numpy oracle (oracle/) against golden vectors generated from the reference itself
-(tools/make_golden.py).  Two levels:
+(tests/golden/make_golden.py).  Two levels:
   * float64: the oracle re-run in double must agree with the reference re-run in double to ~1e-7 — this pins the
     restated SEMANTICS (bin edges, biased/unbiased variance, tap weights, reduction sets ...) free of rounding noise;
   * float32: the oracle in the reference's arithmetic type must agree within fp32 rounding-noise tolerances.

@@ -1,5 +1,5 @@
 """Pins the numpy restatement of the frozen RAFT flow network (oracle/np_raft.py) against vectors produced by the
-reference's RAFT_core (tools/make_golden.py: case_raft).  CPU only."""
+reference's RAFT_core (tests/golden/make_golden.py: case_raft).  CPU only."""
 import numpy as np
 
 from oracle import np_raft

@@ -61,6 +61,34 @@ def test_conv2d_fwd_bwd(dev, case):
         _close(bd.grad, br.grad, 1e-5, "conv bias grad %s" % (case,))
 
 
+@pytest.mark.parametrize("n,c,h,w,k", [(2, 256, 16, 24, 64),   # interior 128x128 / 96-row tiles: accumulators seeded
+                                       (1, 64, 9, 13, 32),     # ragged: every tile takes the guarded epilogue
+                                       (3, 1024, 20, 20, 256)])
+def test_conv_bn_act_skip_gradient_is_folded_into_dgrad(dev, n, c, h, w, k):
+    """Bottleneck entry (models/resnet.py:75-90): x feeds conv1 AND the skip.  With skip_out the skip gradient is added
+    in conv1's data-gradient epilogue (vspw_conv2d_bwd_data_acc); the total must equal autograd's sum of both paths."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(77 + c)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(k, c, 1, 1, generator=g) * (2.0 / c) ** 0.5
+    gamma, beta = torch.rand(k, generator=g) + 0.5, torch.randn(k, generator=g) * 0.1
+    gz, gs = torch.randn(n, k, h, w, generator=g), torch.randn(n, c, h, w, generator=g)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    zr = F.relu(F.batch_norm(F.conv2d(xr, wr), None, None, gamma, beta, True, 0.1, 1e-5))
+    torch.autograd.backward([zr, xr * 1.0], [gz, gs])  # second output: the skip path
+    xd = x.to(dev).requires_grad_(True)
+    wd = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rm, rv = torch.zeros(k, device=dev), torch.ones(k, device=dev)
+    zd, skip = ops.conv_bn_act(xd, wd, None, gamma.to(dev), beta.to(dev), rm, rv, training=True, relu=True,
+                               skip_out=True)
+    assert skip.shape == xd.shape and skip.grad_fn is zd.grad_fn  # the skip output belongs to conv1's node
+    torch.autograd.backward([zd, skip], [gz.to(dev), gs.to(dev)])
+    _close(zd, zr, 1e-4, "fwd")
+    _close(xd.grad, xr.grad, 2e-4, "dgrad + skip gradient")
+    _close(wd.grad, wr.grad, 3e-4, "wgrad")
+
+
 @pytest.mark.parametrize("shape,relu,res,train", [
     ((4, 64, 9, 11), True, False, True),
     ((2, 256, 7, 5), True, True, True),

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(1024) void bn_finalize_partials_kernel(
 }
 
 // sums[i] = sum_z part[z][i] (fp64) and the fp32 parameter gradients dbeta = sums[0][:], dgamma = sums[1][:]
-__global__ __launch_bounds__(1024) void reduce_partials_pg_kernel(const double* __restrict__ part,
+template <typename T>
+__global__ __launch_bounds__(1024) void reduce_partials_pg_kernel(const T* __restrict__ part,
                                                                   double* __restrict__ sums, float* __restrict__ dgamma,
                                                                   float* __restrict__ dbeta, int splits, int c) {
     __shared__ double red[16][64];
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(1024) void reduce_partials_pg_kernel(const double* 
     double a = 0;
     if (col < n) {
 #pragma unroll 8
-        for (int z = ty; z < splits; z += 16) a += part[(size_t)z * n + col];
+        for (int z = ty; z < splits; z += 16) a += (double)part[(size_t)z * n + col];
     }
     red[ty][tx] = a;
     __syncthreads();
@@ -549,8 +550,16 @@ extern "C" int vspw_bn_bwd_reduce_pg(const float* dz, const float* z, const floa
     double* part = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(gx, gy), dim3(RED_TX, RED_TY), 0, vspw_stream(stream), dz, z, x, mean,
                        invstd, chan_mask, rows, c, rows_per_image, relu, part);
-    hipLaunchKernelGGL(reduce_partials_pg_kernel, dim3(vspw_cdiv(2 * c, 64)), dim3(1024), 0, vspw_stream(stream), part,
-                       sums, dgamma, dbeta, gy, c);
+    hipLaunchKernelGGL(reduce_partials_pg_kernel<double>, dim3(vspw_cdiv(2 * c, 64)), dim3(1024), 0,
+                       vspw_stream(stream), (const double*)part, sums, dgamma, dbeta, gy, c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_bn_bwd_reduce_partials_f32(const float* part, int tiles, int c, double* sums, float* dgamma,
+                                               float* dbeta, void* stream) {
+    if (!part || !sums || tiles <= 0 || c <= 0) return VSPW_EINVAL;
+    hipLaunchKernelGGL(reduce_partials_pg_kernel<float>, dim3(vspw_cdiv(2 * c, 64)), dim3(1024), 0, vspw_stream(stream),
+                       part, sums, dgamma, dbeta, tiles, c);
     return vspw_launch_status();
 }
 

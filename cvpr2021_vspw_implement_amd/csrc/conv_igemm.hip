@@ -33,6 +33,15 @@ struct IgemmNT {
     float* dst;         // [m][ldd]
     float* stat_part;   // optional [tiles_m][2][nout] per-tile column sum / sumsq (fused BN stats)
     const float* addend;  // optional [m][ldd], added in the epilogue (skip-connection gradient folded into the dgrad)
+    // Fused BatchNorm-backward front end (data gradient only): the tensor this launch produces is dL/dz of the
+    // conv+BN+ReLU node that produced this conv's input z.  With relu_src = z and bn_y = that node's pre-BN conv output:
+    //   g = (z > 0) ? dx : 0  is what gets stored, and stat_part receives the per-tile column sums of g and of
+    //   g * (bn_y - bn_mean) * bn_invstd  - the two reductions of batch_norm backward - so that node needs no separate
+    // reduction pass and no ReLU-mask read.  All three are [m][ldd] / [nout]; all or none are set.
+    const float* relu_src;
+    const float* bn_y;
+    const float* bn_mean;
+    const float* bn_invstd;
     int nb, h, w, c;    // src dims
     int oh, ow;         // pixel grid of the GEMM M dimension
     int kh, kw, stride, pad, padw, dil;  // pad: rows (H), padw: columns (W)
@@ -521,6 +530,35 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
             csum[j] = 0.f;
             csq[j] = 0.f;
             const float bv = (p.bias != nullptr) ? p.bias[n0 + wn * 32 * WN + j * 32 + l31] : 0.f;
+            if (p.relu_src != nullptr) {
+                // fused BN-backward front end: first every load (z and the pre-BN activations), then the stores - loads
+                // interleaved with stores would be serialised (dst may alias them as far as the compiler knows)
+                const char* zbase = reinterpret_cast<const char*>(p.relu_src + (size_t)m0 * p.ldd + n0);
+                const char* ybase = reinterpret_cast<const char*>(p.bn_y + (size_t)m0 * p.ldd + n0);
+                const int col = n0 + wn * 32 * WN + j * 32 + l31;
+                const float mu = p.bn_mean[col], is = p.bn_invstd[col];
+                float xh[WM][16];
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const size_t uoff = ((size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldd + j * 32) * 4;
+                        const float zv = *reinterpret_cast<const float*>(zbase + uoff + lane_off);
+                        xh[i][r] = *reinterpret_cast<const float*>(ybase + uoff + lane_off);
+                        if (!(zv > 0.f)) acc[i][j][r] = 0.f;
+                    }
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const size_t uoff = ((size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldd + j * 32) * 4;
+                        const float v = acc[i][j][r];
+                        *reinterpret_cast<float*>(dbase + uoff + lane_off) = v;
+                        csum[j] += v;
+                        csq[j] += v * ((xh[i][r] - mu) * is);
+                    }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -549,9 +587,14 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
                     if (cok && row < p.m) {
                         float v = nt_act(acc[i][j][r] + bv, p.act);
                         if (p.addend != nullptr) v += p.addend[(size_t)row * p.ldd + col];
+                        float w2 = v;
+                        if (p.relu_src != nullptr) {  // fused BN-backward front end (see IgemmNT)
+                            if (!(p.relu_src[(size_t)row * p.ldd + col] > 0.f)) v = 0.f;
+                            w2 = (p.bn_y[(size_t)row * p.ldd + col] - p.bn_mean[col]) * p.bn_invstd[col];
+                        }
                         p.dst[(size_t)row * p.ldd + col] = v;
                         csum[j] += v;
-                        csq[j] += v * v;
+                        csq[j] += v * w2;
                     }
                 }
             }
@@ -1153,6 +1196,7 @@ static int conv_geometry_ok(const vspw_conv_desc* d) {
 
 static bool fill_fwd_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr; p.addend = nullptr;
+    p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
     p.nb = d->n; p.h = d->h; p.w = d->w; p.c = d->c;
     p.oh = d->oh; p.ow = d->ow;
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;
@@ -1200,8 +1244,16 @@ extern "C" int vspw_conv2d_fwd_ex(const vspw_conv_desc* d, const float* x, long 
     return launch_igemm_nt(p, vspw_stream(stream));
 }
 
+struct BnFront {
+    const float* relu_src;
+    const float* bn_y;
+    const float* bn_mean;
+    const float* bn_invstd;
+    float* stat_part;
+};
 static int conv2d_bwd_data_impl(const vspw_conv_desc* d, const float* dy, const float* wT, const float* addend,
-                                float* dx, void* stream);
+                                float* dx, void* stream, const BnFront* bn = nullptr);
+static bool fill_bwd_data_params(const vspw_conv_desc* d, IgemmNT& p);
 
 extern "C" int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, const float* wT, float* dx,
                                     void* stream) {
@@ -1214,23 +1266,53 @@ extern "C" int vspw_conv2d_bwd_data_acc(const vspw_conv_desc* d, const float* dy
     return conv2d_bwd_data_impl(d, dy, wT, addend, dx, stream);
 }
 
-static int conv2d_bwd_data_impl(const vspw_conv_desc* d, const float* dy, const float* wT, const float* addend,
-                                float* dx, void* stream) {
-    if (!conv_geometry_ok(d) || !dy || !wT || !dx) return VSPW_EINVAL;
+extern "C" size_t vspw_conv2d_bwd_data_bn_partials(const vspw_conv_desc* d) {
+    // rows of the per-tile partial buffer of vspw_conv2d_bwd_data_bn; 0 = this geometry cannot take the fused path
+    if (!conv_geometry_ok(d)) return 0;
     IgemmNT p;
-    p.src = dy; p.wt = wT; p.bias = nullptr; p.dst = dx; p.stat_part = nullptr; p.addend = addend;
+    if (!fill_bwd_data_params(d, p)) return 0;
+    bool v2;
+    const int rows = nt_tile_rows(nt_decide(p, v2));
+    return v2 ? (size_t)((p.m + rows - 1) / rows) : 0;
+}
+
+extern "C" int vspw_conv2d_bwd_data_bn(const vspw_conv_desc* d, const float* dy, const float* wT, const float* addend,
+                                       const float* relu_src, const float* bn_y, const float* bn_mean,
+                                       const float* bn_invstd, float* dx, float* stat_part, void* stream) {
+    if (!relu_src || !bn_y || !bn_mean || !bn_invstd || !stat_part) return VSPW_EINVAL;
+    if (vspw_conv2d_bwd_data_bn_partials(d) == 0) return VSPW_EINVAL;
+    BnFront bn = {relu_src, bn_y, bn_mean, bn_invstd, stat_part};
+    return conv2d_bwd_data_impl(d, dy, wT, addend, dx, stream, &bn);
+}
+
+static bool fill_bwd_data_params(const vspw_conv_desc* d, IgemmNT& p) {
+    p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr; p.addend = nullptr;
+    p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
     p.nb = d->n; p.h = d->oh; p.w = d->ow; p.c = d->k;   // gather over dY
     p.oh = d->h; p.ow = d->w;                              // rows are input pixels
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;
     p.mode = 1;
     p.nout = d->c; p.ldd = d->c;
     long long m = (long long)d->n * d->h * d->w;
-    if (m > 0x7fffffffLL) return VSPW_EINVAL;
+    if (m > 0x7fffffffLL) return false;
     p.m = (int)m;
     p.kdim = d->kh * d->kw * d->k;
     p.vec = (d->k % 4 == 0) ? 1 : 0;
     p.lds = d->k;
     p.act = 0;
+    return true;
+}
+
+static int conv2d_bwd_data_impl(const vspw_conv_desc* d, const float* dy, const float* wT, const float* addend,
+                                float* dx, void* stream, const BnFront* bn) {
+    if (!conv_geometry_ok(d) || !dy || !wT || !dx) return VSPW_EINVAL;
+    IgemmNT p;
+    if (!fill_bwd_data_params(d, p)) return VSPW_EINVAL;
+    p.src = dy; p.wt = wT; p.dst = dx; p.addend = addend;
+    if (bn) {
+        p.relu_src = bn->relu_src; p.bn_y = bn->bn_y; p.bn_mean = bn->bn_mean; p.bn_invstd = bn->bn_invstd;
+        p.stat_part = bn->stat_part;
+    }
     return launch_igemm_nt(p, vspw_stream(stream));
 }
 

@@ -27,6 +27,17 @@ def _residual_branch(block, x):
     return vnn.conv_bn_act(x, block.downsample[0], block.downsample[1], relu=False)
 
 
+class _BlockSequential(nn.Sequential):
+    """nn.Sequential of residual blocks (same child names, hence the reference's state_dict keys).  Block i's output is
+    read by block i+1 and nothing else, which is what Bottleneck.forward(sole_consumer=True) needs to know; the first
+    block's input and the last block's output may have other readers (feature maps handed to the decoders)."""
+
+    def forward(self, x):
+        for i, blk in enumerate(self):
+            x = blk(x, sole_consumer=True) if (i > 0 and isinstance(blk, Bottleneck)) else blk(x)
+        return x
+
+
 class BasicBlock(nn.Module):
     """reference models/resnet.py:24-53"""
 
@@ -64,16 +75,19 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x):
+    def forward(self, x, sole_consumer=False):
+        """sole_consumer: nothing but this block reads x (true for every block but the first of a layer, see
+        _BlockSequential) - lets conv1's data gradient carry the previous block's batch-norm backward reductions."""
         # the skip connection is taken from conv1's node (skip_out): in backward its gradient is added in conv1's
         # data-gradient epilogue instead of by a separate accumulation pass over the block input
         skip = x
         if x.requires_grad and torch.is_grad_enabled():
-            out, skip = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True, skip_out=True)
+            out, skip = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True, skip_out=True, fuse_input=sole_consumer)
         else:
             out = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
-        out = vnn.conv_bn_act(out, self.conv2, self.bn2, relu=True)
-        return vnn.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=_residual_branch(self, skip))
+        out = vnn.conv_bn_act(out, self.conv2, self.bn2, relu=True, fuse_input=True)   # conv1's output: only read here
+        return vnn.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=_residual_branch(self, skip),
+                               fuse_input=True)
 
 
 class ResNet(nn.Module):
@@ -117,12 +131,12 @@ class ResNet(nn.Module):
         self.inplanes = planes * block.expansion
         for _ in range(1, blocks):
             layers.append(block(self.inplanes, planes))
-        return nn.Sequential(*layers)
+        return _BlockSequential(*layers)
 
     def stem(self, x):
         x = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
-        x = vnn.conv_bn_act(x, self.conv2, self.bn2, relu=True)
-        x = vnn.conv_bn_act(x, self.conv3, self.bn3, relu=True)
+        x = vnn.conv_bn_act(x, self.conv2, self.bn2, relu=True, fuse_input=True)  # each stem output has one reader
+        x = vnn.conv_bn_act(x, self.conv3, self.bn3, relu=True, fuse_input=True)
         return ops.max_pool3x3s2(x)
 
     def forward(self, x):

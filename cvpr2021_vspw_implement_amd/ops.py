@@ -8,6 +8,7 @@ like the reference while the kernels see [pixel rows][channel columns].
 There is no CPU fallback: a CPU tensor raises (SURVEY.md §8b "Errors").
 """
 import ctypes
+import os
 
 import torch
 
@@ -140,19 +141,31 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False):
     return y, part, d
 
 
-def conv2d_backward_data(dy, w, d, addend=None):
-    """dx = conv_backward_input(dy, w) [+ addend, folded into the GEMM epilogue]."""
+def conv2d_backward_data(dy, w, d, addend=None, bn_front=None):
+    """dx = conv_backward_input(dy, w) [+ addend, folded into the GEMM epilogue].
+    bn_front = (z, link): additionally apply the ReLU mask of the node that produced this conv's input z and leave the
+    two batch-norm-backward reductions of that node in link.partials (see BNLink); returns the masked gradient."""
     k, c, kh, kw = w.shape
     wT = torch.empty((c, kh, kw, k), device=w.device, dtype=torch.float32)
     _C.call("vspw_weight_transpose", _p(w), _p(wT), k, kh * kw, c, _stream())
     dx = empty_nhwc(d.n, d.c, d.h, d.w, dy.device)
+    if addend is not None:
+        addend = to_nhwc(addend)
+        if tuple(addend.shape) != tuple(dx.shape):
+            raise RuntimeError("conv2d_backward_data: addend %s vs dx %s" % (tuple(addend.shape), tuple(dx.shape)))
+    if bn_front is not None:
+        z, link = bn_front
+        tiles = _C.query("vspw_conv2d_bwd_data_bn_partials", ctypes.byref(d))
+        part = torch.empty((tiles, 2, d.c), device=dy.device, dtype=torch.float32)
+        with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "dgrad")):
+            _C.call("vspw_conv2d_bwd_data_bn", ctypes.byref(d), _p(dy), _p(wT), _p(addend), _p(z), _p(link.y),
+                    _p(link.mean), _p(link.invstd), _p(dx), _p(part), _stream())
+        link.partials, link.g = part, dx
+        return dx
     with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "dgrad")):
         if addend is None:
             _C.call("vspw_conv2d_bwd_data", ctypes.byref(d), _p(dy), _p(wT), _p(dx), _stream())
         else:
-            addend = to_nhwc(addend)
-            if tuple(addend.shape) != tuple(dx.shape):
-                raise RuntimeError("conv2d_backward_data: addend %s vs dx %s" % (tuple(addend.shape), tuple(dx.shape)))
             _C.call("vspw_conv2d_bwd_data_acc", ctypes.byref(d), _p(dy), _p(wT), _p(addend), _p(dx), _stream())
     return dx
 
@@ -322,13 +335,34 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, mas
                                 relu, stat_part)
 
 
+class BNLink(object):
+    """Side channel between a conv+BN+ReLU node (owner) and the ONE conv node that consumes its output z.  In backward
+    the consumer's data-gradient GEMM already touches every element of dL/dz; given the owner's pre-BN activations and
+    batch statistics it applies the owner's ReLU mask and produces the owner's two batch-norm-backward reductions in
+    its epilogue (vspw_conv2d_bwd_data_bn), so the owner skips its reduction pass and the mask read.  Only valid when
+    the consumer is the sole user of z - the model code asserts that by passing fuse_input=True."""
+
+    __slots__ = ("y", "mean", "invstd", "rows", "c", "partials", "g")
+
+    def __init__(self):
+        self.y = self.mean = self.invstd = self.partials = self.g = None
+        self.rows = self.c = 0
+
+
+_bn_fusion = {"enabled": os.environ.get("VSPW_NO_BN_FUSION", "0") != "1", "fused_nodes": 0}
+
+
+def set_bn_backward_fusion(enabled):
+    _bn_fusion["enabled"] = bool(enabled)
+
+
 class ConvBNActFn(torch.autograd.Function):
     """conv2d -> BN(train/eval) -> [+residual] -> [ReLU] -> [Dropout2d mask] as ONE autograd node, with the
     BatchNorm statistics accumulated in the convolution epilogue (no separate pass over the conv output)."""
 
     @staticmethod
     def forward(ctx, x, w, cbias, gamma, beta, running_mean, running_var, residual, mask, stride, pad, dil, training,
-                momentum, eps, relu, skip_out=False):
+                momentum, eps, relu, skip_out=False, in_link=None, out_link=None):
         _require_gpu(x, "conv_bn_act")
         x = to_nhwc(x)
         fuse_stats = training
@@ -380,6 +414,15 @@ class ConvBNActFn(torch.autograd.Function):
         ctx.has_cbias = cbias is not None
         ctx.save_for_backward(x, w, y, z if relu else None, gamma, coef, mask)
         ctx.skip_out = bool(skip_out)
+        ctx.out_link = None
+        if out_link is not None and training and relu and mask is None:
+            out_link.y, out_link.mean, out_link.invstd, out_link.rows, out_link.c = y, mean, invstd, rows, c
+            ctx.out_link = out_link
+        ctx.in_link = None
+        if in_link is not None and in_link.y is not None and in_link.c == x.shape[1] and \
+                in_link.rows == x.shape[0] * x.shape[2] * x.shape[3] and \
+                _C.query("vspw_conv2d_bwd_data_bn_partials", ctypes.byref(d)) > 0:
+            ctx.in_link = in_link
         if skip_out:
             # second output = the input itself (autograd turns it into a view with this node as grad_fn): the block's
             # skip connection is routed through here so that its gradient is added in this conv's dgrad epilogue
@@ -399,37 +442,66 @@ class ConvBNActFn(torch.autograd.Function):
         relu = 1 if ctx.relu else 0
         train = 1 if ctx.training else 0
         sums = torch.empty((2, c), device=dev, dtype=torch.float64)
-        nbytes = _C.query("vspw_bn_bwd_workspace", rows, c)
-        ws = _ws(nbytes, dev)
         dgamma = torch.empty(c, device=dev, dtype=torch.float32) if ctx.needs_input_grad[3] else None
         dbeta = torch.empty(c, device=dev, dtype=torch.float32) if ctx.needs_input_grad[4] else None
-        # reduction + the LOCAL parameter gradients (dgamma/dbeta are taken before any cross-rank exchange)
-        _C.call("vspw_bn_bwd_reduce_pg", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(mask), rows, c, h * wd, relu,
-                _p(sums), _p(dgamma), _p(dbeta), _p(ws), nbytes, st)
-        if ctx.training and ctx.world != 1:
-            _all_reduce_sums(sums)
+        link = ctx.out_link
+        fused = link is not None and link.partials is not None and link.g is not None and \
+            link.g.data_ptr() == dz.data_ptr() and tuple(link.g.shape) == tuple(dz.shape)
         dy = empty_nhwc(n, c, h, wd, dev)
-        dres = empty_nhwc(n, c, h, wd, dev) if (ctx.has_res and ctx.needs_input_grad[7]) else None
-        _C.call("vspw_bn_bwd_apply", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums),
-                ctypes.c_double(ctx.count), _p(mask), rows, c, h * wd, relu, train, _p(dy), _p(dres), None, None, st)
+        if fused:
+            # the consumer's data gradient already masked dz with this node's ReLU and left the two reductions behind
+            _bn_fusion["fused_nodes"] += 1
+            part = link.partials
+            _C.call("vspw_bn_bwd_reduce_partials_f32", _p(part), part.shape[0], c, _p(sums), _p(dgamma), _p(dbeta), st)
+            if ctx.training and ctx.world != 1:
+                _all_reduce_sums(sums)
+            _C.call("vspw_bn_bwd_apply", _p(dz), None, _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums),
+                    ctypes.c_double(ctx.count), None, rows, c, h * wd, 0, train, _p(dy), None, None, None, st)
+            dres = dz if (ctx.has_res and ctx.needs_input_grad[7]) else None  # dres = g, which dz already is
+        else:
+            nbytes = _C.query("vspw_bn_bwd_workspace", rows, c)
+            ws = _ws(nbytes, dev)
+            # reduction + the LOCAL parameter gradients (dgamma/dbeta are taken before any cross-rank exchange)
+            _C.call("vspw_bn_bwd_reduce_pg", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(mask), rows, c, h * wd,
+                    relu, _p(sums), _p(dgamma), _p(dbeta), _p(ws), nbytes, st)
+            if ctx.training and ctx.world != 1:
+                _all_reduce_sums(sums)
+            dres = empty_nhwc(n, c, h, wd, dev) if (ctx.has_res and ctx.needs_input_grad[7]) else None
+            _C.call("vspw_bn_bwd_apply", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums),
+                    ctypes.c_double(ctx.count), _p(mask), rows, c, h * wd, relu, train, _p(dy), _p(dres), None, None,
+                    st)
+        if link is not None:
+            link.partials = link.g = link.y = link.mean = link.invstd = None  # one backward per forward
         if not is_nhwc(w):
             w = w.contiguous(memory_format=torch.channels_last)
         dx = dw = dcb = None
         if ctx.needs_input_grad[0]:
-            dx = conv2d_backward_data(dy, w, d, addend=dskip if ctx.skip_out else None)
+            front = None
+            if ctx.in_link is not None and ctx.in_link.y is not None and _bn_fusion["enabled"]:
+                front = (x, ctx.in_link)
+            dx = conv2d_backward_data(dy, w, d, addend=dskip if ctx.skip_out else None, bn_front=front)
         if ctx.needs_input_grad[1]:
             dw = conv2d_backward_weight(dy, x, d)
         if ctx.has_cbias and ctx.needs_input_grad[2]:
             dcb = colsum(rows, c, dy)
-        return (dx, dw, dcb, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None)
+        return (dx, dw, dcb, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None,
+                None, None)
 
 
 def conv_bn_act(x, w, cbias, gamma, beta, running_mean, running_var, residual=None, mask=None, stride=1, pad=0,
-                dil=1, training=True, momentum=0.1, eps=1e-5, relu=True, skip_out=False):
+                dil=1, training=True, momentum=0.1, eps=1e-5, relu=True, skip_out=False, fuse_input=False):
     """skip_out: also return the input as a second output (see ConvBNActFn.forward) - use THAT tensor for the skip
-    connection of a residual block and its gradient is folded into this convolution's data-gradient epilogue."""
-    return ConvBNActFn.apply(x, w, cbias, gamma, beta, running_mean, running_var, residual, mask, stride, pad, dil,
-                             training, momentum, eps, relu, skip_out)
+    connection of a residual block and its gradient is folded into this convolution's data-gradient epilogue.
+    fuse_input: the caller guarantees this conv is the ONLY consumer of x; if x came out of a conv+BN+ReLU node, that
+    node's batch-norm backward reductions are then produced by this conv's data gradient (see BNLink)."""
+    grad = torch.is_grad_enabled() and _bn_fusion["enabled"]
+    in_link = getattr(x, "_vspw_link", None) if (fuse_input and grad and x.requires_grad) else None
+    out_link = BNLink() if (grad and training and relu and mask is None) else None
+    out = ConvBNActFn.apply(x, w, cbias, gamma, beta, running_mean, running_var, residual, mask, stride, pad, dil,
+                            training, momentum, eps, relu, skip_out, in_link, out_link)
+    if out_link is not None and out_link.y is not None:
+        (out[0] if skip_out else out)._vspw_link = out_link
+    return out
 
 
 # --------------------------------------------------------------------------------------------------- pooling

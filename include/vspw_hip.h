@@ -64,6 +64,17 @@ int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, const float* 
  * `out += residual`) is added in the GEMM epilogue instead of by a separate pass.  addend has dx's shape/layout. */
 int vspw_conv2d_bwd_data_acc(const vspw_conv_desc* d, const float* dy, const float* wT, const float* addend, float* dx,
                              void* stream);
+/* Data gradient with the BatchNorm-backward FRONT END of the node that produced this conv's input fused into the
+ * epilogue (models/resnet.py:75-90 chains conv -> bn -> relu -> conv): relu_src = that node's output z (this conv's
+ * saved input), bn_y / bn_mean / bn_invstd = its pre-BN activations and batch statistics.  Stores
+ * g = (z > 0) ? dx : 0 into dx and the per-tile column sums of g and g*(bn_y-mean)*invstd into stat_part
+ * [vspw_conv2d_bwd_data_bn_partials(d)][2][c]; that node then runs vspw_bn_bwd_reduce_partials_f32 + vspw_bn_bwd_apply
+ * (relu = 0) and needs neither the reduction pass nor the mask read.  addend may be NULL.  _partials returns 0 when
+ * the geometry cannot take this path. */
+size_t vspw_conv2d_bwd_data_bn_partials(const vspw_conv_desc* d);
+int vspw_conv2d_bwd_data_bn(const vspw_conv_desc* d, const float* dy, const float* wT, const float* addend,
+                            const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
+                            float* dx, float* stat_part, void* stream);
 /* dw [k][kh][kw][c] = conv2d_backward_weight(dy, x); split-K over pixels, deterministic reduction. */
 size_t vspw_conv2d_bwd_weight_workspace(const vspw_conv_desc* d);
 int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, const float* x, float* dw, void* ws,
@@ -109,6 +120,10 @@ int vspw_bn_bwd_reduce(const float* dz, const float* z, const float* x, const fl
 int vspw_bn_bwd_reduce_pg(const float* dz, const float* z, const float* x, const float* mean, const float* invstd,
                           const float* chan_mask, long long rows, int c, long long rows_per_image, int relu,
                           double* sums, float* dgamma, float* dbeta, void* ws, size_t ws_bytes, void* stream);
+/* The same two sums (+ local parameter gradients) from the per-tile fp32 partials that vspw_conv2d_bwd_data_bn wrote:
+ * no pass over the activations at all. */
+int vspw_bn_bwd_reduce_partials_f32(const float* part, int tiles, int c, double* sums, float* dgamma, float* dbeta,
+                                    void* stream);
 /* dx = gamma*invstd*(g - sums0/count - xhat*sums1/count) (training) or gamma*invstd*g (eval);
  * dres = g (optional); dgamma = sums1, dbeta = sums0 (as fp32). */
 int vspw_bn_bwd_apply(const float* dz, const float* z, const float* x, const float* mean, const float* invstd,

@@ -87,12 +87,22 @@ class GradReducer:
             if t.is_floating_point() or t.dtype == torch.long:
                 dist.broadcast(t.data, src=src, group=self.group)
 
+    def _launch(self, bi):
+        """Gather the bucket's gradients into its flat buffer with ONE multi-tensor copy, then start the all-reduce."""
+        bucket = self.buckets[bi]
+        have = [p for p in bucket if p.grad is not None and p.grad.data_ptr() != self.slots[id(p)].data_ptr()]
+        if have:
+            torch._foreach_copy_([self.slots[id(p)] for p in have], [p.grad for p in have])
+        for p in bucket:
+            if p.grad is None:
+                self.slots[id(p)].zero_()
+        self.handles[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def _on_grad(self, p):
         bi = self.owner[id(p)]
-        self.slots[id(p)].copy_(p.grad)
         self.pending[bi] -= 1
         if self.pending[bi] == 0:
-            self.handles[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._launch(bi)
 
     def wait(self):
         """Finish the outstanding all-reduces and write the averaged gradients back. Call before optimizer.step()."""
@@ -101,16 +111,14 @@ class GradReducer:
         inv = 1.0 / self.world
         for bi, bucket in enumerate(self.buckets):
             if self.pending[bi] != 0:  # parameters that got no gradient this step: reduce what is there
-                for p in bucket:
-                    if p.grad is None:
-                        self.slots[id(p)].zero_()
-                self.handles[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group,
-                                                   async_op=True)
+                self._launch(bi)
             self.handles[bi].wait()
             self.flat[bi].mul_(inv)
             for p in bucket:
                 if p.grad is not None:
-                    p.grad.copy_(self.slots[id(p)])
+                    # the averaged gradient IS the bucket slot (same shape and strides as the parameter): no copy
+                    # back.  The drivers call zero_grad() every step (train_clip2.py:87), which drops these views.
+                    p.grad = self.slots[id(p)]
             self.pending[bi] = len(bucket)
             self.handles[bi] = None
 

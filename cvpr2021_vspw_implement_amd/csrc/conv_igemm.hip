@@ -259,8 +259,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (cok && row < p.m) {
-                    float v = nt_act(acc[i][j][r] + bv, p.act);
-                    if (p.addend != nullptr) v += p.addend[(size_t)row * p.ldd + col];
+                    float t = acc[i][j][r] + bv;
+                    if (p.addend != nullptr) t += p.addend[(size_t)row * p.ldd + col];
+                    const float v = nt_act(t, p.act);  // act(conv + bias + addend): residual add, then ReLU
                     p.dst[(size_t)row * p.ldd + col] = v;
                     csum[j] += v;
                     csq[j] += v * v;
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
     // interior tile (uniform): unguarded epilogue.  With a skip-connection addend the accumulators START from it
     // (C = addend, then C += A*B): its loads are issued here, in the shadow of the first operand tiles, instead of in
     // the epilogue where nothing hides their latency.
-    const bool interior = (m0 + TM <= p.m) & (n0 + TN <= p.nout) & (p.act == 0);
+    const bool interior = (m0 + TM <= p.m) & (n0 + TN <= p.nout) & (p.act <= 1);  // none or ReLU
     const unsigned lane_off = (unsigned)((wm * 32 * WM + 4 * lh) * p.ldd + wn * 32 * WN + l31) * 4u;
     if (p.addend != nullptr && interior) {
         const char* abase = reinterpret_cast<const char*>(p.addend + (size_t)m0 * p.ldd + n0);
@@ -564,7 +565,8 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const size_t uoff = ((size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldd + j * 32) * 4;  // uniform
-                    const float v = acc[i][j][r] + bv;
+                    float v = acc[i][j][r] + bv;
+                    if (p.act == 1) v = fmaxf(v, 0.f);
                     *reinterpret_cast<float*>(dbase + uoff + lane_off) = v;
                     csum[j] += v;
                     csq[j] += v * v;
@@ -585,8 +587,9 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                     if (cok && row < p.m) {
-                        float v = nt_act(acc[i][j][r] + bv, p.act);
+                        float v = acc[i][j][r] + bv;
                         if (p.addend != nullptr) v += p.addend[(size_t)row * p.ldd + col];
+                        v = nt_act(v, p.act);  // act(conv + bias + addend)
                         float w2 = v;
                         if (p.relu_src != nullptr) {  // fused BN-backward front end (see IgemmNT)
                             if (!(p.relu_src[(size_t)row * p.ldd + col] > 0.f)) v = 0.f;
@@ -1237,7 +1240,8 @@ extern "C" int vspw_conv2d_fwd(const vspw_conv_desc* d, const float* x, const fl
 }
 
 extern "C" int vspw_conv2d_fwd_ex(const vspw_conv_desc* d, const float* x, long long ldx, const float* w,
-                                  const float* bias, int act, float* y, long long ldy, void* stream) {
+                                  const float* bias, const float* addend, int act, float* y, long long ldy,
+                                  void* stream) {
     if (!conv_geometry_ok(d) || !x || !w || !y || ldx < d->c || ldy < d->k || act < 0 || act > 3) return VSPW_EINVAL;
     if (ldx > 0x7fffffffLL || ldy > 0x7fffffffLL) return VSPW_EINVAL;
     IgemmNT p;
@@ -1246,6 +1250,7 @@ extern "C" int vspw_conv2d_fwd_ex(const vspw_conv_desc* d, const float* x, long 
     p.lds = (int)ldx;
     p.ldd = (int)ldy;
     p.act = act;
+    p.addend = addend;  // [m][ldy], same layout as y
     p.vec = (d->c % 4 == 0 && ldx % 4 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0) ? 1 : 0;
     return launch_igemm_nt(p, vspw_stream(stream));
 }

@@ -103,6 +103,21 @@ __global__ void chan_scale_kernel(const float* __restrict__ g, const float* __re
     for (; i < total; i += stride) out[i] = w[(int)(i % c)] * g[i];
 }
 
+// out[row][col] = s[row] * w[row][col]: folds the eval-mode BatchNorm scale into conv weights [Cout][KH*KW*Cin]
+__global__ __launch_bounds__(256) void row_scale_kernel(const float* __restrict__ w, const float* __restrict__ s,
+                                                        float* __restrict__ out, long long rows, long long cols) {
+    const long long total = rows * cols;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) out[i] = s[i / cols] * w[i];
+}
+// out[c] = a[c] * s[c] + t[c]: the conv bias seen through BatchNorm
+__global__ void fold_bias_kernel(const float* __restrict__ a, const float* __restrict__ s, const float* __restrict__ t,
+                                 float* __restrict__ out, int c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < c) out[i] = a[i] * s[i] + t[i];
+}
+
 // ---- flow warp -------------------------------------------------------------------------------------------------
 // flowwarp(x, flo): vgrid = meshgrid + flo; g = 2*vgrid/max(dim-1,1) - 1; grid_sample(x, g, bilinear, zeros,
 // align_corners=False) i.e. pixel coordinate p = ((g+1)*dim - 1)/2.  Note the (dim-1) normalisation combined with
@@ -264,6 +279,19 @@ extern "C" int vspw_chan_scale(const float* g, const float* w, float* out, long 
     if (!g || !w || !out || rows <= 0 || c <= 0) return VSPW_EINVAL;
     hipLaunchKernelGGL(chan_scale_kernel, dim3(vspw_stream_grid(rows * c, 256)), dim3(256), 0, vspw_stream(stream), g,
                        w, out, rows, c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_bn_fold_weights(const float* w, const float* cbias, const float* scale, const float* shift,
+                                    float* w_out, float* bias_out, int k, long long cols, void* stream) {
+    if (!w || !scale || !shift || !w_out || !bias_out || k <= 0 || cols <= 0) return VSPW_EINVAL;
+    hipStream_t st = vspw_stream(stream);
+    hipLaunchKernelGGL(row_scale_kernel, dim3(vspw_stream_grid((long long)k * cols, 256)), dim3(256), 0, st, w, scale,
+                       w_out, (long long)k, cols);
+    if (cbias)
+        hipLaunchKernelGGL(fold_bias_kernel, dim3(vspw_cdiv(k, 256)), dim3(256), 0, st, cbias, scale, shift, bias_out, k);
+    else
+        hipMemcpyAsync(bias_out, shift, (size_t)k * sizeof(float), hipMemcpyDeviceToDevice, st);
     return vspw_launch_status();
 }
 

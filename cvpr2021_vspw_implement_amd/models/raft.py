@@ -110,7 +110,7 @@ def _conv(x, n, h, w, c, ldx, wt, bias, kh, kw, stride, pad, act, y, ldy):
     oh = (h + 2 * ph - (kh - 1) - 1) // stride + 1
     ow = (w + 2 * pw - (kw - 1) - 1) // stride + 1
     d = ConvDesc(n, h, w, c, oh, ow, k, kh, kw, stride, ph, 1, pw)
-    _C.call("vspw_conv2d_fwd_ex", ctypes.byref(d), x, ldx, _p(wt), _p(bias), act, y, ldy, _stream())
+    _C.call("vspw_conv2d_fwd_ex", ctypes.byref(d), x, ldx, _p(wt), _p(bias), None, act, y, ldy, _stream())
     return oh, ow
 
 

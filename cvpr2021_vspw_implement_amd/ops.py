@@ -335,6 +335,47 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, mas
                                 relu, stat_part)
 
 
+_infer_fold = {"enabled": os.environ.get("VSPW_NO_INFER_FOLD", "0") != "1", "cache": {}}
+
+
+def set_inference_folding(enabled):
+    _infer_fold["enabled"] = bool(enabled)
+
+
+def _conv_bn_folded(x, w, cbias, gamma, beta, running_mean, running_var, residual, stride, pad, dil, eps, relu):
+    """relu?(conv(x, w*scale) + (cbias*scale + shift) [+ residual]) with scale/shift from the running statistics.  The
+    folded weights are cached per weight tensor and rebuilt when any of the tensors they derive from changes."""
+    if not is_nhwc(w):
+        w = w.contiguous(memory_format=torch.channels_last)
+    k, c, kh, kw = w.shape
+    if c != x.shape[1]:
+        raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (x.shape[1], c))
+    srcs = (w, cbias, gamma, beta, running_mean, running_var)
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in srcs) + (float(eps),)
+    ent = _infer_fold["cache"].get(id(w))
+    st = _stream()
+    if ent is None or ent[0] != key:
+        coef = torch.empty((4, k), device=x.device, dtype=torch.float32)
+        _C.call("vspw_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(coef[0]),
+                _p(coef[1]), _p(coef[2]), _p(coef[3]), k, st)
+        wf = torch.empty((k, kh, kw, c), device=x.device, dtype=torch.float32)
+        bf = torch.empty(k, device=x.device, dtype=torch.float32)
+        _C.call("vspw_bn_fold_weights", _p(w), _p(cbias), _p(coef[2]), _p(coef[3]), _p(wf), _p(bf), k, kh * kw * c, st)
+        ent = (key, wf, bf)
+        _infer_fold["cache"][id(w)] = ent
+    _, wf, bf = ent
+    d = _conv_desc(x, k, kh, kw, stride, pad, dil)
+    z = empty_nhwc(d.n, k, d.oh, d.ow, x.device)
+    if residual is not None:
+        residual = to_nhwc(residual)
+        if tuple(residual.shape) != tuple(z.shape):
+            raise RuntimeError("conv_bn_act: residual %s vs output %s" % (tuple(residual.shape), tuple(z.shape)))
+    with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "fwd")):
+        _C.call("vspw_conv2d_fwd_ex", ctypes.byref(d), _p(x), c, _p(wf), _p(bf), _p(residual), 1 if relu else 0, _p(z),
+                k, st)
+    return z
+
+
 class BNLink(object):
     """Side channel between a conv+BN+ReLU node (owner) and the ONE conv node that consumes its output z.  In backward
     the consumer's data-gradient GEMM already touches every element of dL/dz; given the owner's pre-BN activations and
@@ -494,6 +535,13 @@ def conv_bn_act(x, w, cbias, gamma, beta, running_mean, running_var, residual=No
     connection of a residual block and its gradient is folded into this convolution's data-gradient epilogue.
     fuse_input: the caller guarantees this conv is the ONLY consumer of x; if x came out of a conv+BN+ReLU node, that
     node's batch-norm backward reductions are then produced by this conv's data gradient (see BNLink)."""
+    if not training and mask is None and not torch.is_grad_enabled() and _infer_fold["enabled"]:
+        # inference: BatchNorm is an affine map per output channel - fold its scale into the weights, pass its shift as
+        # the bias, add the residual and apply the ReLU in the GEMM epilogue: one launch, no pass over y
+        _require_gpu(x, "conv_bn_act")
+        x = to_nhwc(x)
+        z = _conv_bn_folded(x, w, cbias, gamma, beta, running_mean, running_var, residual, stride, pad, dil, eps, relu)
+        return (z, x) if skip_out else z
     grad = torch.is_grad_enabled() and _bn_fusion["enabled"]
     in_link = getattr(x, "_vspw_link", None) if (fuse_input and grad and x.requires_grad) else None
     out_link = BNLink() if (grad and training and relu and mask is None) else None

@@ -55,9 +55,11 @@ size_t vspw_conv2d_stats_partials(const vspw_conv_desc* d);
 /* Inference-side variant used by the frozen RAFT flow network (RAFT_core/update.py:6-136, extractor.py:6-190): the
  * input may be a channel slice of a wider NHWC buffer (pixel stride ldx floats >= c; torch.cat call sites such as
  * update.py:24,29,44,47 become slot writes), the output is written with row stride ldy floats >= k, and the epilogue
- * applies act(conv + bias): 0 none, 1 relu, 2 sigmoid, 3 tanh (update.py:14,26-28,84-92). */
+ * applies act(conv + bias + addend): 0 none, 1 relu, 2 sigmoid, 3 tanh (update.py:14,26-28,84-92); addend (may be
+ * NULL) has y's layout.  Eval-mode conv + BatchNorm (+ residual) + ReLU of the segmentation nets also runs through
+ * here, with the BN scale folded into the weights and its shift passed as the bias (ops.ConvBNActFn, inference). */
 int vspw_conv2d_fwd_ex(const vspw_conv_desc* d, const float* x, long long ldx, const float* w, const float* bias,
-                       int act, float* y, long long ldy, void* stream);
+                       const float* addend, int act, float* y, long long ldy, void* stream);
 /* dx = conv2d_backward_input(dy, w).  wT is the [c][kh][kw][k] copy of w made by vspw_weight_transpose. */
 int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, const float* wT, float* dx, void* stream);
 /* dx = conv2d_backward_input(dy, w) + addend: the gradient arriving over the skip connection (models/resnet.py:75-90:
@@ -106,6 +108,10 @@ int vspw_bn_finalize_partials_f32(const float* part, int tiles, double count, co
 /* Eval-mode coefficients from the running statistics. */
 int vspw_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float eps, float* mean, float* invstd, float* scale, float* shift, int c, void* stream);
+/* Inference: conv followed by eval-mode BatchNorm is one conv with w_out[k][:] = scale[k]*w[k][:] and
+ * bias_out[k] = (cbias ? cbias[k]*scale[k] : 0) + shift[k]  (then vspw_conv2d_fwd_ex adds the residual and the ReLU). */
+int vspw_bn_fold_weights(const float* w, const float* cbias, const float* scale, const float* shift, float* w_out,
+                         float* bias_out, int k, long long cols, void* stream);
 /* z = [relu]( x*scale + shift [+ residual] ) [* chan_mask[image][c]]   (chan_mask = Dropout2d mask/(1-p)). */
 int vspw_bn_apply(const float* x, const float* scale, const float* shift, const float* residual,
                   const float* chan_mask, float* z, long long rows, int c, long long rows_per_image, int relu,

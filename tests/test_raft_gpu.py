@@ -132,7 +132,7 @@ def test_conv_ex_slices_padding_activation(dev, kh, kw, pad, c, k, act):
     tb = torch.from_numpy(bias).to(dev)
     y = torch.full((n, h, w, ldy), -7.0, device=dev)
     d = ConvDesc(n, h, w, c, h, w, k, kh, kw, 1, pad[0], 1, pad[1])
-    _C.call("vspw_conv2d_fwd_ex", ctypes.byref(d), ctypes.c_void_p(tx.data_ptr() + 32), ldx, _p(tw), _p(tb), act,
+    _C.call("vspw_conv2d_fwd_ex", ctypes.byref(d), ctypes.c_void_p(tx.data_ptr() + 32), ldx, _p(tw), _p(tb), None, act,
             ctypes.c_void_p(y.data_ptr() + 16), ldy, _stream())
     got = y.cpu().numpy()
     assert np.abs(got[..., 4:4 + k].transpose(0, 3, 1, 2) - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())

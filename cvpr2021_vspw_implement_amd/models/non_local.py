@@ -4,7 +4,6 @@ f = theta^T phi / N has no softmax, so y = f g is evaluated as two MFMA GEMMs ov
 that NHWC memory provides for free (N = H*W, or T*H*W for the spatio-temporal block).  The 1/N is applied to g
 (N x 128) instead of f (N x N): same value up to fp32 rounding, N/128 times less traffic.
 """
-import torch
 import torch.nn as nn
 
 from .. import nn as vnn

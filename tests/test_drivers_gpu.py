@@ -61,6 +61,28 @@ def test_clip_psp_train_checkpoint_eval(dev, tree, tmp_path):
     assert np.isnan(out["VC"]) or 0.0 <= out["VC"] <= 1.0
     pngs = os.listdir(str(tmp_path / "pred" / "v_b"))
     assert len(pngs) == 9  # one palette PNG per frame of the video
+    # resume (train_clip2.py:347-357 reads ./resume/model_epoch_N.pth + opt_epoch_N.pth relative to the cwd)
+    import shutil
+
+    os.makedirs(str(tmp_path / "run" / "resume"))
+    for f in ("model_epoch_2.pth", "opt_epoch_2.pth"):
+        shutil.copy(os.path.join(save, f), str(tmp_path / "run" / "resume" / f))
+    cwd = os.getcwd()
+    os.chdir(str(tmp_path / "run"))
+    try:
+        rargs = T.build_parser().parse_args([
+            "--method", "clip_psp", "--dataroot", tree, "--saveroot", save, "--batchsize", "3", "--cropsize", "40",
+            "--clip_num", "4", "--dilation2", "3,6,9", "--totalepoch", "3", "--ckpt_every", "3", "--lr", "0.01",
+            "--resume_epoch", "2", "--validation", "false", "--gpus", "0"])
+        rargs.cfg = args.cfg
+        rcfg = _cfg("ppm_deepsup_clip")
+        T.prepare(rargs, rcfg)
+        rcfg.MODEL.arch_encoder = "resnet50dilated"
+        rhist = T.main(rcfg, [0], rargs)
+    finally:
+        os.chdir(cwd)
+    assert len(rhist["train"]["loss"]) == 1 and np.isfinite(rhist["train"]["loss"][0])  # only epoch 3 ran
+    assert os.path.exists(os.path.join(save, "model_epoch_3.pth"))
 
 
 def test_netwarp_train_step_with_hip_raft(dev, tree, tmp_path):

@@ -137,3 +137,22 @@ def test_conv_ex_slices_padding_activation(dev, kh, kw, pad, c, k, act):
     got = y.cpu().numpy()
     assert np.abs(got[..., 4:4 + k].transpose(0, 3, 1, 2) - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
     assert (got[..., :4] == -7.0).all() and (got[..., 4 + k:] == -7.0).all()  # neighbouring slots untouched
+
+
+def test_raft_full_size_constant_flow_property(dev):
+    """At the NetWarp working size (480x856 = 479x853 zero-padded, B = 2, 20 iterations): with the flow head's last
+    conv zeroed and its bias set to (a, b) every iteration adds exactly (a, b), so flow_low = 20*(a, b) everywhere and,
+    convex upsampling being a convex combination, flow_up = 8 * flow_low away from the zero-padded border."""
+    fx = golden("raft_basic")
+    m, _ = _raft(dev, fx)
+    with torch.no_grad():
+        m.update_block.flow_head.conv2.weight.zero_()
+        m.update_block.flow_head.conv2.bias.copy_(torch.tensor([0.25, -0.125], device=dev))
+    g = torch.Generator().manual_seed(9)
+    a = (torch.rand(2, 3, 480, 856, generator=g) * 255).to(dev)
+    b = (torch.rand(2, 3, 480, 856, generator=g) * 255).to(dev)
+    low, up = m(a, b, iters=20, test_mode=True)
+    assert low.shape == (2, 2, 60, 107) and up.shape == (2, 2, 480, 856)
+    ref = torch.tensor([5.0, -2.5], device=dev).view(1, 2, 1, 1)
+    assert (low - ref).abs().max().item() < 1e-5
+    assert (up[:, :, 8:-8, 8:-8] - 8 * ref).abs().max().item() < 2e-4

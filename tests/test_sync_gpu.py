@@ -23,7 +23,8 @@ def _free_port():
 def _build(dev):
     from helpers import build, load_det, zero_dropout
 
-    mod = build("seg", "resnet18dilated", "ppm_deepsup", 512)
+    # bottleneck encoder: exercises the fused BN-backward front end (ops.BNLink) and the folded skip gradient too
+    mod = build("seg", "resnet50dilated", "ppm_deepsup", 2048)
     load_det(mod)
     zero_dropout(mod)
     return mod.to(dev).train()

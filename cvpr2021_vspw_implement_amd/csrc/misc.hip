@@ -291,7 +291,7 @@ extern "C" int vspw_bn_fold_weights(const float* w, const float* cbias, const fl
     if (cbias)
         hipLaunchKernelGGL(fold_bias_kernel, dim3(vspw_cdiv(k, 256)), dim3(256), 0, st, cbias, scale, shift, bias_out, k);
     else
-        hipMemcpyAsync(bias_out, shift, (size_t)k * sizeof(float), hipMemcpyDeviceToDevice, st);
+        (void)hipMemcpyAsync(bias_out, shift, (size_t)k * sizeof(float), hipMemcpyDeviceToDevice, st);
     return vspw_launch_status();
 }
 

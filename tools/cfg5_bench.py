@@ -1,0 +1,75 @@
+"""Training-step timing of the non-local configurations of BASELINE.json cfg 5: (5a) SegmentationModule(R101 dilated,
+nonlocal2d), B = 2 frames of 479x479; (5b) Non_local3d, T = 7 frames, B = 2 clips (affinity 25 200 x 25 200 per clip)."""
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cvpr2021_vspw_implement_amd import models as M  # noqa: E402
+from cvpr2021_vspw_implement_amd import optim  # noqa: E402
+
+
+def timeit(step, reps):
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        loss = step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3, loss
+
+
+def main():
+    dev = torch.device("cuda:0")
+    torch.manual_seed(304)
+    S, K = 479, 124
+    crit = torch.nn.NLLLoss(ignore_index=255)
+    # 5a
+    enc = M.ModelBuilder.build_encoder(arch="resnet101dilated", fc_dim=2048)
+    dec = M.ModelBuilder.build_decoder(arch="nonlocal2d", fc_dim=2048, num_class=K)
+    net = M.SegmentationModule(enc, dec, crit, None).to(dev).train()
+    opt = torch.optim.SGD(net.parameters(), lr=0.002, momentum=0.9)
+    img = torch.randn(2, 3, S, S, device=dev)
+    lab = torch.randint(0, K, (2, 1, S, S), device=dev).float()
+
+    def step_a():
+        net.zero_grad()
+        loss, _ = net({"img_data": img, "seg_label": lab})
+        loss.backward()
+        opt.step()
+        return loss
+
+    ms, loss = timeit(step_a, 6)
+    print(json.dumps({"workload": "cfg5a SegmentationModule(R101 dilated, nonlocal2d) train, B=2, 479x479",
+                      "ms_per_step": round(ms, 2), "finite": bool(torch.isfinite(loss).item())}))
+    del net, opt
+    torch.cuda.empty_cache()
+    # 5b
+    T = 7
+    args = types.SimpleNamespace(num_class=K, clip_num=T)
+    enc = M.ModelBuilder.build_encoder(arch="resnet101dilated", fc_dim=2048)
+    net3 = M.Non_local3d(args, enc, crit).to(dev).train()
+    opt3 = optim.create_optimizers(net3, lr=0.002)
+    imgs = [torch.randn(2, 3, S, S, device=dev) for _ in range(T)]
+    labs = [torch.randint(0, K, (2, 1, S, S), device=dev).float() for _ in range(T)]
+
+    def step_b():
+        net3.zero_grad()
+        loss, _ = net3({"clipimgs_data": list(imgs), "cliplabels_data": list(labs)})
+        loss.backward()
+        opt3.step()
+        return loss
+
+    ms, loss = timeit(step_b, 3)
+    print(json.dumps({"workload": "cfg5b Non_local3d (R101 dilated) train, T=7, B=2 clips, 479x479",
+                      "ms_per_step": round(ms, 2), "clips_per_s": round(2 / ms * 1e3, 2),
+                      "finite": bool(torch.isfinite(loss).item())}))
+
+
+if __name__ == "__main__":
+    main()

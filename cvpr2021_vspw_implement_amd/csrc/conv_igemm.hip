@@ -641,6 +641,12 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
 static int nt_pick_tile(long long m, int nout) {
     if (nout <= 64) return (((m + 127) / 128) >= 1024) ? 21 : 11;
     const long long tn = (nout + 127) / 128;
+    // small problems (the RAFT update block: 12 840 pixels): with 64x128 tiles there would be at most two workgroups
+    // per CU - one wave per SIMD, nothing to hide LDS / barrier latency behind.  64x64 tiles quadruple the number of
+    // workgroups; the lost operand reuse does not matter at sizes that live in L2.
+    // measured on the RAFT forward (B = 2, 480x856): 27.3 -> 24.3 ms with the threshold at two workgroups per CU
+    static const int small_wg = getenv("VSPW_SMALL_WG") ? atoi(getenv("VSPW_SMALL_WG")) : 520;
+    if (((m + 63) / 64) * tn <= small_wg) return 11;
     const int rows[3] = {128, 96, 64};
     const int code[3] = {22, 31, 12};
     const double eff[3] = {1.0, 0.97, 0.92};

@@ -1083,19 +1083,40 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
         }
         const float* Ac = As[cur];
         const float* Bc = Bs[cur];
+        // Fragments.  A wave's MFMA block i covers rows 2*l31 + i (WM == 2) rather than i*32 + l31: the two values a
+        // lane needs for one k are then 8 contiguous bytes, and two k-steps (LDS rows 2 apart) come from ONE
+        // ds_read2st64_b64 - 16 LDS reads per 64 MFMAs instead of 32, a wait every other MFMA group.  Same for B / WN.
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int s = 0; s < BK / 2; ++s) {
-            float a[WM], b[WN];
-#pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = Ac[(2 * s + lh) * TM + wm * 32 * WM + i * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = Bc[(2 * s + lh) * TN + wn * 32 * WN + j * 32 + l31];
+        for (int sp = 0; sp < BK / 4; ++sp) {
+            float a0[WM], a1[WM], b0[WN], b1[WN];
+            if (WM == 2) {
+                const f32x2 t0 = *reinterpret_cast<const f32x2*>(&Ac[(4 * sp + lh) * TM + wm * 64 + 2 * l31]);
+                const f32x2 t1 = *reinterpret_cast<const f32x2*>(&Ac[(4 * sp + 2 + lh) * TM + wm * 64 + 2 * l31]);
+                a0[0] = t0[0]; a0[WM - 1] = t0[1]; a1[0] = t1[0]; a1[WM - 1] = t1[1];
+            } else {
+                a0[0] = Ac[(4 * sp + lh) * TM + wm * 32 + l31];
+                a1[0] = Ac[(4 * sp + 2 + lh) * TM + wm * 32 + l31];
+            }
+            if (WN == 2) {
+                const f32x2 t0 = *reinterpret_cast<const f32x2*>(&Bc[(4 * sp + lh) * TN + wn * 64 + 2 * l31]);
+                const f32x2 t1 = *reinterpret_cast<const f32x2*>(&Bc[(4 * sp + 2 + lh) * TN + wn * 64 + 2 * l31]);
+                b0[0] = t0[0]; b0[WN - 1] = t0[1]; b1[0] = t1[0]; b1[WN - 1] = t1[1];
+            } else {
+                b0[0] = Bc[(4 * sp + lh) * TN + wn * 32 + l31];
+                b1[0] = Bc[(4 * sp + 2 + lh) * TN + wn * 32 + l31];
+            }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            if (s == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            if (sp == 1) {
                 if (NBUF == 2) {
                     store_tile(As[(NBUF - 1) & (cur ^ 1)], Bs[(NBUF - 1) & (cur ^ 1)]);  // tile kt+1
                     advance();
@@ -1107,15 +1128,17 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     }
 
     float* out = p.part + (size_t)split * p.k * p.ncols;
+    // (row / column of accumulator element r of block (i, j) under the interleaved fragment mapping above)
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-        const int col = n0 + wn * 32 * WN + j * 32 + l31;
+        const int col = n0 + wn * 32 * WN + (WN == 2 ? 2 * l31 + j : l31);
         if (col >= p.ncols) continue;
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = m0 + wm * 32 * WM + (WM == 2 ? 2 * rr + i : rr);
                 if (row < p.k) out[(size_t)row * p.ncols + col] = acc[i][j][r];
             }
         }

@@ -9,7 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 
-template <int FLAGS>
+template <int FLAGS, int PAIR>
 __global__ __launch_bounds__(256) void gemm_tn(const float* __restrict__ A, const float* __restrict__ B,
                                                float* __restrict__ C, int M, int N, int K, int chunk) {
     constexpr int TM = 128, TN = 128;
@@ -53,13 +53,44 @@ __global__ __launch_bounds__(256) void gemm_tn(const float* __restrict__ A, cons
     for (int kt = 0; kt < nk; ++kt) {
         if (FLAGS & 2) store_tile();
         if (FLAGS & 4) __syncthreads();
+        if (PAIR) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int sp = 0; sp < BK / 4; ++sp) {
+                // two MFMA k-steps per fetch: rows (4sp + lh) and (4sp + 2 + lh), 8 bytes each -> ds_read2_b64
+                const f32x2 a0 = *reinterpret_cast<const f32x2*>(&As[(4 * sp + lh) * TM + wm * 64 + 2 * l31]);
+                const f32x2 a1 = *reinterpret_cast<const f32x2*>(&As[(4 * sp + 2 + lh) * TM + wm * 64 + 2 * l31]);
+                const f32x2 b0 = *reinterpret_cast<const f32x2*>(&Bs[(4 * sp + lh) * TN + wn * 64 + 2 * l31]);
+                const f32x2 b1 = *reinterpret_cast<const f32x2*>(&Bs[(4 * sp + 2 + lh) * TN + wn * 64 + 2 * l31]);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i], b0[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                if (sp == 1 && (FLAGS & 1)) {
+                    int k = (kt + 1) * BK;
+                    load_tile(k < chunk ? k : 0);
+                }
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             if (FLAGS & 8) {
+                if (PAIR) {
+                    // MFMA block i of a wave covers rows 2*l31 + i (instead of i*32 + l31): one 8-byte read feeds both
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 a2 = *reinterpret_cast<const f32x2*>(&As[(2 * s + lh) * TM + wm * 64 + 2 * l31]);
+                    const f32x2 b2 = *reinterpret_cast<const f32x2*>(&Bs[(2 * s + lh) * TN + wn * 64 + 2 * l31]);
+                    a[0] = a2[0]; a[1] = a2[1]; b[0] = b2[0]; b[1] = b2[1];
+                } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) a[i] = As[(2 * s + lh) * TM + wm * 64 + i * 32 + l31];
+                    for (int i = 0; i < 2; ++i) a[i] = As[(2 * s + lh) * TM + wm * 64 + i * 32 + l31];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) b[j] = Bs[(2 * s + lh) * TN + wn * 64 + j * 32 + l31];
+                    for (int j = 0; j < 2; ++j) b[j] = Bs[(2 * s + lh) * TN + wn * 64 + j * 32 + l31];
+                }
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -70,6 +101,7 @@ __global__ __launch_bounds__(256) void gemm_tn(const float* __restrict__ A, cons
                 int k = (kt + 1) * BK;
                 load_tile(k < chunk ? k : 0);
             }
+        }
         }
         if (FLAGS & 4) __syncthreads();
     }
@@ -87,17 +119,17 @@ __global__ __launch_bounds__(256) void gemm_tn(const float* __restrict__ A, cons
     }
 }
 
-template <int FLAGS>
+template <int FLAGS, int PAIR = 0>
 static void run(const char* name, const float* A, const float* B, float* C, int M, int N, int K, int splits) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     dim3 grid((M / 128) * (N / 128), splits);
     const int chunk = K / splits;
-    for (int i = 0; i < 2; ++i) gemm_tn<FLAGS><<<grid, 256>>>(A, B, C, M, N, K, chunk);
+    for (int i = 0; i < 2; ++i) gemm_tn<FLAGS, PAIR><<<grid, 256>>>(A, B, C, M, N, K, chunk);
     hipEventRecord(e0);
     const int reps = 5;
-    for (int i = 0; i < reps; ++i) gemm_tn<FLAGS><<<grid, 256>>>(A, B, C, M, N, K, chunk);
+    for (int i = 0; i < reps; ++i) gemm_tn<FLAGS, PAIR><<<grid, 256>>>(A, B, C, M, N, K, chunk);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
@@ -119,6 +151,7 @@ int main() {
     hipMemcpy(B, h.data(), (size_t)K * N * 4, hipMemcpyHostToDevice);
     for (int splits : {18, 24}) {
         run<15>("full", A, B, C, M, N, K, splits);
+        run<15, 1>("full, 8-byte paired fragments", A, B, C, M, N, K, splits);
         run<14>("no global loads", A, B, C, M, N, K, splits);
         run<12>("no global loads, no ds_write", A, B, C, M, N, K, splits);
         run<8>("ds_read + mfma only (no barrier)", A, B, C, M, N, K, splits);

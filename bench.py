@@ -7,18 +7,26 @@ B=2 clips of T=5 frames, 479x479 crops, 124 classes per GPU: forward, fused loss
 (N>1) and the SGD update — every FLOP in the hand-written HIP kernels of libvspw_hip.so.  Synthetic data (seed 304)
 is resident in HBM before the timed region; weights are random-init (no network for checkpoints).
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N --steps K --warmup W      # N > 1 without WORLD_SIZE: re-executes itself as N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
+Execution mode (--mode): "graph" records the step once into a hipGraph and replays it (one hipGraphLaunch per step
+instead of ~1 400 Python-issued launches; cvpr2021_vspw_implement_amd/graph.py), "eager" issues every launch from
+Python, "auto" = graph when the step can be captured (always at N=1; at N>1 after a preflight that captures and
+replays one RCCL all-reduce), else eager.
+
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events recorded on the launch stream around every
 launch of the dominant kernel (igemm_nt_kernel: all convolution forward and data-gradient GEMMs, ~2/3 of the step's
-FLOPs) inside the timed region; `cpu_baseline` times the numpy oracle (a port of the reference's arithmetic, test
-infrastructure) on a bounded sample on rank 0 at N=1.
+FLOPs) on timed steps executed eagerly inside the timed region (graph mode: the last timed step; eager mode: first,
+middle, last); `cpu_baseline` times the numpy oracle (a port of the reference's arithmetic, test infrastructure) on a
+bounded sample on rank 0 at N=1.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import types
@@ -26,11 +34,51 @@ import types
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz
 K_CLASSES, T_FRAMES, B_CLIPS, CROP = 124, 5, 2, 479
 GFLOP_PER_CLIP = 5785.0  # cfg 3 forward+backward, conv/bmm FLOPs
+REFERENCE_CPU = {"clips_per_s": 0.024, "cores": 8,
+                 "what": "the reference's own PyTorch-CPU path (ATen/oneDNN), TCB-PSP R101 T=5 B=2 479^2 fwd+bwd, "
+                         "83.5 s/step on the build container's 8 vCPU (BASELINE.md section 2) - context, not timed here"}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", default="auto", choices=["auto", "graph", "eager"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-size", type=int, default=CROP,
+                    help="crop of the CPU-baseline sample (B=2 clips x 1 frame); 479 = the workload's own frame size")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-host-probe", action="store_true")
+    ap.add_argument("--kernel-report", default="", help="write a per-shape GEMM efficiency table to this file "
+                                                        "(every timed step runs eagerly with per-launch events)")
+    ap.add_argument("--method", default="clip_psp", choices=["clip_psp", "clip_ocr"])
+    return ap.parse_args()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` outside torchrun: become the launcher of N ranks (one process per GPU)."""
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < n:
+        raise RuntimeError("--gpus %d but only %d GPU(s) are visible (hipGetDeviceCount)" % (n, have))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def measured_traffic(kernel):
@@ -50,21 +98,24 @@ def measured_traffic(kernel):
         return None, None
 
 
-def make_inputs(dev, seed):
+def make_inputs(dev, seed, crop=CROP):
+    import torch
+
     g = torch.Generator().manual_seed(seed)
-    imgs = [torch.randn(B_CLIPS, 3, CROP, CROP, generator=g).to(dev) for _ in range(T_FRAMES)]
+    imgs = [torch.randn(B_CLIPS, 3, crop, crop, generator=g).to(dev) for _ in range(T_FRAMES)]
     labs = []
     for _ in range(T_FRAMES):
-        lab = torch.randint(0, K_CLASSES, (B_CLIPS, 1, CROP, CROP), generator=g).float()
-        lab[torch.rand(B_CLIPS, 1, CROP, CROP, generator=g) < 0.05] = 255.0
+        lab = torch.randint(0, K_CLASSES, (B_CLIPS, 1, crop, crop), generator=g).float()
+        lab[torch.rand(B_CLIPS, 1, crop, crop, generator=g) < 0.05] = 255.0
         labs.append(lab.to(dev))
     return imgs, labs
 
 
-def cpu_baseline(budget_note=True):
-    """Numpy-oracle port timed on the host cores: TCB-PSP R101 forward+backward on a bounded sample
-    (B=2 clips x 1 of the 5 frames at 239x239, i.e. 1/5 of the frames at 1/4.02 of the pixels); cost is linear in
-    frames and (to first order) in pixels, so clips/s = 2 / (t * 5 * (479/239)^2)."""
+def cpu_baseline(S=CROP):
+    """Numpy-oracle port timed on the host cores: TCB-PSP R101 forward+backward on B=2 clips x 1 of the 5 frames at
+    SxS (default: the workload's own 479x479 frames, no pixel extrapolation).  The encoder / deep-supervision cost is
+    linear in the number of frames, so one B=2, T=5 step = 5x this sample: clips/s = 2 / (5 t) (x (479/S)^2 if a
+    smaller S was asked for)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     from helpers import build, det_numpy_state
@@ -73,7 +124,6 @@ def cpu_baseline(budget_note=True):
     from oracle.det_init import det_input, det_labels
 
     O.set_dtype(np.float32)
-    S = 239
     mod = build("clip_psp", "resnet101dilated")
     sd = det_numpy_state(mod)
     imgs = [det_input("bench:0", (B_CLIPS, 3, S, S))]
@@ -93,31 +143,64 @@ def cpu_baseline(budget_note=True):
             cores = max(blas)
     except Exception:
         pass
-    return {"value": B_CLIPS / (dt * scale), "unit": "clips/s", "cores": cores, "kind": "port",
-            "sample": "numpy oracle (oracle/np_models.clip_psp, R101) fwd+bwd on B=2 clips x 1 frame at %dx%d: %.1f s; "
-                      "scaled x%.1f (5 frames, (479/%d)^2 pixels) to one B=2,T=5,479^2 step" % (S, S, dt, scale, S)}
+    return {"value": B_CLIPS / (dt * scale), "unit": "clips/s", "cores": cores, "host_cpus": os.cpu_count(),
+            "kind": "port",
+            "sample": "numpy oracle (oracle/np_models.clip_psp, R101) fwd+bwd on B=2 clips x 1 frame at %dx%d: %.1f s "
+                      "on %d BLAS threads; x%.2f (5 frames%s) = one B=2,T=5,479^2 step"
+                      % (S, S, dt, cores, scale, "" if S == CROP else ", (479/%d)^2 pixels" % S),
+            "reference_cpu_context": REFERENCE_CPU}
+
+
+def rccl_capture_preflight(dev):
+    """Can this RCCL build record an all-reduce into a hipGraph and replay it?  (N>1 only.)"""
+    import torch
+    import torch.distributed as dist
+
+    try:
+        t = torch.ones(1024, device=dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dist.all_reduce(t)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        t.fill_(1.0)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            dist.all_reduce(t)
+        g.replay()
+        g.replay()
+        torch.cuda.synchronize()
+        w = dist.get_world_size()
+        ok = bool(abs(float(t[0].item()) - float(w) ** 2) < 1e-3)  # capture records only; two replays
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write("rccl capture preflight failed: %r\n" % (e,))
+        ok = False
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() > 0.5)
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--kernel-report", default="", help="write a per-shape GEMM efficiency table to this file")
-    ap.add_argument("--method", default="clip_psp", choices=["clip_psp", "clip_ocr"])
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+
+    import torch
 
     from cvpr2021_vspw_implement_amd import distributed as vdist
     from cvpr2021_vspw_implement_amd import models as M
     from cvpr2021_vspw_implement_amd import ops, optim
+    from cvpr2021_vspw_implement_amd.graph import GraphedStep
 
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU fallback")
     rank, local_rank, world = vdist.init_from_env()
     if world != args.gpus:
-        raise RuntimeError("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise RuntimeError("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if local_rank >= torch.cuda.device_count():
+        raise RuntimeError("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank,
+                                                                                 torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -137,11 +220,10 @@ def main():
     imgs, labs = make_inputs(dev, 304 + rank)
     max_iters = 1000
 
-    def step(it):
+    def step_body(im, lb):
         net.zero_grad()
-        optim.adjust_learning_rate(opt, it, max_iters, 0.002)
-        feed = {"img_data": imgs[0], "seg_label": labs[0], "clipimgs_data": list(imgs[1:]),
-                "cliplabels_data": list(labs[1:]), "step": it}
+        feed = {"img_data": im[0], "seg_label": lb[0], "clipimgs_data": list(im[1:]),
+                "cliplabels_data": list(lb[1:]), "step": 0}
         loss, acc = model(feed)
         loss = loss.mean()
         loss.backward()
@@ -149,28 +231,55 @@ def main():
         opt.step()
         return loss
 
+    def eager_step(it, im=imgs, lb=labs):
+        optim.adjust_learning_rate(opt, it, max_iters, 0.002)
+        return step_body(im, lb)
+
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    collectives = world > 1 or force
+    mode = args.mode
+    if mode == "auto":
+        mode = "graph"
+        if collectives and not rccl_capture_preflight(dev):
+            mode = "eager"
+    graphed = None
+    if mode == "graph":
+        optim.adjust_learning_rate(opt, 0, max_iters, 0.002)
+        graphed = GraphedStep(lambda: step_body(imgs, labs), warmup=2)
+
+    def run_step(it, eager=False):
+        if graphed is None or eager:
+            return eager_step(it)
+        optim.adjust_learning_rate(opt, it, max_iters, 0.002)
+        opt.set_lrs()
+        return graphed.replay()
+
     for i in range(args.warmup):
-        loss = step(i)
+        loss = run_step(i)
+    if graphed is not None and not args.no_kernel_timing:
+        loss = run_step(args.warmup, eager=True)  # warm the eager path too (allocator, lazily built tables)
     barrier()
-    # per-launch HIP events (two per GEMM launch) cost ~2 % of the step: record them on a sample of the timed steps
-    # (first, middle, last third) unless a full per-shape report was asked for
+    # per-launch HIP events (two per GEMM launch) need eagerly issued launches: graph mode runs the LAST timed step
+    # eagerly, eager mode samples first / middle / last (the events cost ~2 % of a step); --kernel-report: every step
     if args.no_kernel_timing:
         timed_steps = set()
-    elif args.kernel_report or args.steps <= 3:
+    elif args.kernel_report or args.steps <= 2:
         timed_steps = set(range(args.steps))
+    elif graphed is not None:
+        timed_steps = {args.steps - 1}
     else:
         timed_steps = {0, args.steps // 2, args.steps - 1}
     ops.kernel_timer(False)
     ops.kernel_timer_reset()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        ops.kernel_timer(i in timed_steps, reset=False)
-        loss = step(args.warmup + i)
+        ev = i in timed_steps
+        ops.kernel_timer(ev, reset=False)
+        loss = run_step(args.warmup + 1 + i, eager=ev)
     host_enqueue = time.perf_counter() - t0  # host time to enqueue all K steps (GPU still running)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -211,6 +320,26 @@ def main():
                         "gflop_per_launch": round(flops / len(recs) / 1e9, 3),
                         "share_of_step_time": round(ms * 1e-3 / len(timed_steps) / (elapsed / args.steps), 3)}
 
+    # Host cost of ISSUING one eager step with GPU back-pressure excluded: the same launch sequence on 95x95 crops,
+    # where the kernels take a few ms in total and the step time is the Python/ctypes/hipLaunch time itself.
+    host_probe = None
+    if not args.no_host_probe and rank == 0 and world == 1:
+        pim, plb = make_inputs(dev, 9, crop=95)
+        for _ in range(2):
+            eager_step(max_iters // 2, pim, plb)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        n_probe = 5
+        for _ in range(n_probe):
+            eager_step(max_iters // 2, pim, plb)
+        issue = time.perf_counter() - tp
+        torch.cuda.synchronize()
+        total = time.perf_counter() - tp
+        host_probe = {"eager_issue_ms_per_step": round(issue / n_probe * 1e3, 2),
+                      "eager_step_ms_at_95x95": round(total / n_probe * 1e3, 2),
+                      "what": "same launch sequence (TCB-PSP R101, T=5, B=2) on 95x95 crops: GPU work is negligible, so "
+                              "this is the host time to issue one eager step without queue back-pressure"}
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         clips_per_s = world * B_CLIPS * args.steps / elapsed
@@ -232,14 +361,17 @@ def main():
                        if args.method == "clip_psp" else
                        "TCB-OCR (ClipOCRNet, resnet101dilated) train step: T=5, B=2/GPU, 479x479, 124 classes",
                        "global_batch_clips": world * B_CLIPS, "frames_per_step_per_gpu": T_FRAMES * B_CLIPS,
-                       "parallelism": "dp%d" % world, "sync_bn": world > 1 or force},
+                       "parallelism": "dp%d" % world, "sync_bn": collectives,
+                       "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                       "execution": "hipGraph replay" if graphed is not None else "eager launches"},
             "e2e_mfma_frac": round(GFLOP_PER_CLIP * 1e9 * clips_per_s / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
             "last_loss": round(last_loss, 5),
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2),
+            "host_probe": host_probe,
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_size)
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256) void seg_nll_fwd_acc_kernel(const float* __res
     if (threadIdx.x < 4) {
         double a = 0;
         for (int j = 0; j < (int)(blockDim.x >> 6); ++j) a += red[j][threadIdx.x];
+        if (threadIdx.x == 0) a = rint(a * VSPW_NLL_FIXED);  // integer-valued: the atomic sum is order-independent
         if (a != 0) atomicAdd(&out[threadIdx.x], a);
     }
 }
@@ -234,13 +235,15 @@ __global__ __launch_bounds__(256) void seg_nll_fwd_kernel(const float* __restric
         double a = 0;
         for (int j = 0; j < (int)(blockDim.x >> 6); ++j) a += red[j][threadIdx.x];
         const int slot = threadIdx.x == 2 ? 3 : threadIdx.x;
+        if (threadIdx.x == 0) a = rint(a * VSPW_NLL_FIXED);  // integer-valued: the atomic sum is order-independent
         if (a != 0) atomicAdd(&out[slot], a);
     }
 }
 
 // One workgroup per source (feature-resolution) pixel: gather the bilinear adjoint of the per-pixel NLL gradient
-// into K class bins (LDS atomics), then apply the log-softmax Jacobian and write dlogits[K].
+// into K class bins (fixed summation order: bit-reproducible), then apply the log-softmax Jacobian and write dlogits[K].
 #define NLL_MAXK 1024
+#define NLL_CHUNK 512
 __global__ __launch_bounds__(256) void seg_nll_bwd_kernel(const float* __restrict__ logp,
                                                           const int64_t* __restrict__ label,
                                                           const double* __restrict__ fwd_out,
@@ -249,14 +252,14 @@ __global__ __launch_bounds__(256) void seg_nll_bwd_kernel(const float* __restric
                                                           int H, int W, int ignore, float sy, float sx, int jacobian) {
     __shared__ float bins[NLL_MAXK];
     __shared__ float wsum[4];
+    __shared__ float fp_w[NLL_CHUNK];
+    __shared__ int fp_lab[NLL_CHUNK];
     const int tid = threadIdx.x;
     const long long sp = blockIdx.x;
     const int ix = (int)(sp % w);
     long long r = sp / w;
     const int iy = (int)(r % h);
     const int img = (int)(r / h);
-    for (int j = tid; j < k; j += blockDim.x) bins[j] = 0.f;
-    __syncthreads();
     const float ry = (float)H / (float)h, rx = (float)W / (float)w;
     int oy_lo = (int)floorf(((float)iy - 1.f + 0.5f) * ry - 0.5f) - 1;
     int oy_hi = (int)ceilf(((float)iy + 1.f + 0.5f) * ry - 0.5f) + 1;
@@ -271,24 +274,52 @@ __global__ __launch_bounds__(256) void seg_nll_bwd_kernel(const float* __restric
     oy_hi = min(oy_hi, H - 1);
     ox_hi = min(ox_hi, W - 1);
     const int fw = ox_hi - ox_lo + 1, fh = oy_hi - oy_lo + 1;
-    for (int q = tid; q < fw * fh; q += blockDim.x) {
-        const int oy = oy_lo + q / fw, ox = ox_lo + q % fw;
-        int y0, y1, x0, x1;
-        float ly, lx;
-        bilinear_src(oy, sy, h, y0, y1, ly);
-        float wy = 0.f;
-        if (y0 == iy) wy += 1.f - ly;
-        if (y1 == iy) wy += ly;
-        if (wy == 0.f) continue;
-        bilinear_src(ox, sx, w, x0, x1, lx);
-        float wx = 0.f;
-        if (x0 == ix) wx += 1.f - lx;
-        if (x1 == ix) wx += lx;
-        if (wx == 0.f) continue;
-        const long long lab = label[((size_t)img * H + oy) * W + ox];
-        if (lab == (long long)ignore || lab < 0 || lab >= k) continue;
-        atomicAdd(&bins[(int)lab], wy * wx);
+    // Deterministic binning (no atomics): the footprint's (label, weight) pairs are staged in LDS a chunk at a time;
+    // thread j then sums, in footprint order, the weights whose label is one of ITS classes j, j+256, ...
+    float mybin[NLL_MAXK / 256];
+#pragma unroll
+    for (int c = 0; c < NLL_MAXK / 256; ++c) mybin[c] = 0.f;
+    for (int q0 = 0; q0 < fw * fh; q0 += NLL_CHUNK) {
+        for (int e = tid; e < NLL_CHUNK; e += blockDim.x) {
+            const int q = q0 + e;
+            float wgt = 0.f;
+            int lb = -1;
+            if (q < fw * fh) {
+                const int oy = oy_lo + q / fw, ox = ox_lo + q % fw;
+                int y0, y1, x0, x1;
+                float ly, lx;
+                bilinear_src(oy, sy, h, y0, y1, ly);
+                float wy = 0.f;
+                if (y0 == iy) wy += 1.f - ly;
+                if (y1 == iy) wy += ly;
+                bilinear_src(ox, sx, w, x0, x1, lx);
+                float wx = 0.f;
+                if (x0 == ix) wx += 1.f - lx;
+                if (x1 == ix) wx += lx;
+                const long long lab = label[((size_t)img * H + oy) * W + ox];
+                if (wy != 0.f && wx != 0.f && lab != (long long)ignore && lab >= 0 && lab < k) {
+                    wgt = wy * wx;
+                    lb = (int)lab;
+                }
+            }
+            fp_w[e] = wgt;
+            fp_lab[e] = lb;
+        }
+        __syncthreads();
+        const int cnt_e = min(NLL_CHUNK, fw * fh - q0);
+        for (int e = 0; e < cnt_e; ++e) {
+            const int lb = fp_lab[e];  // LDS broadcast
+            if (lb < 0) continue;      // uniform branch
+            const float wv = fp_w[e];
+#pragma unroll
+            for (int c = 0; c < NLL_MAXK / 256; ++c)
+                if (lb == c * 256 + tid) mybin[c] += wv;
+        }
+        __syncthreads();
     }
+#pragma unroll
+    for (int c = 0; c < NLL_MAXK / 256; ++c)
+        if (c * 256 + tid < k) bins[c * 256 + tid] = mybin[c];
     __syncthreads();
     const double cnt = fwd_out[1];
     const float g = cnt > 0 ? -gscale[0] / (float)cnt : 0.f;

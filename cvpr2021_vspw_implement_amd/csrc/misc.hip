@@ -324,9 +324,21 @@ extern "C" int vspw_flowwarp_bwd(const float* dy, const float* x, const float* f
 
 // ---- SGD with momentum / weight decay, `mult` sequential applications -----------------------------------------
 // torch.optim.SGD semantics (train_clip2.py:215-236: momentum 0.9, weight_decay per group, dampening 0, no nesterov)
-// applied `mult` times in a row with the same gradient: the reference's get_*_lr_params generators yield a parameter
-// once per enclosing module, and torch.optim.SGD (1.3.1, a plain Python loop) then updates it once per occurrence.
-//   d = g + wd*p ; buf = first ? d : momentum*buf + d ; p -= lr*buf
+// applied `mult` times in a row: the reference's get_*_lr_params generators yield a parameter once per enclosing
+// module, and torch.optim.SGD of the pinned PyTorch 1.3.1 (README.md:13; a plain Python loop) then updates it once
+// per occurrence.  1.3.1 applies the weight decay IN PLACE on p.grad (`d_p = p.grad.data; d_p.add_(wd, p.data)`), so
+// the r-th occurrence sees g + wd*(p_0 + ... + p_{r-1}): the decay term accumulates across the occurrences.
+//   g += wd*p ; buf = first ? g : momentum*buf + g ; p -= lr*buf        (g lives in a register; p.grad is not rewritten)
+__device__ __forceinline__ void sgd_apply(float& pv, float gv, float& bv, bool have, float lr, float wd,
+                                          float momentum, int mult) {
+    for (int r = 0; r < mult; ++r) {
+        gv = gv + wd * pv;
+        bv = have ? momentum * bv + gv : gv;
+        have = true;
+        pv -= lr * bv;
+    }
+}
+
 __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                        float* __restrict__ buf, long long n, float lr, float wd,
                                                        float momentum, int mult, int first) {
@@ -334,15 +346,8 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* __restrict__ p, co
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         float pv = p[i];
-        const float gv = g[i];
         float bv = first ? 0.f : buf[i];
-        bool have = !first;
-        for (int r = 0; r < mult; ++r) {
-            const float d = gv + wd * pv;
-            bv = have ? momentum * bv + d : d;
-            have = true;
-            pv -= lr * bv;
-        }
+        sgd_apply(pv, g[i], bv, !first, lr, wd, momentum, mult);
         p[i] = pv;
         buf[i] = bv;
     }
@@ -359,10 +364,12 @@ extern "C" int vspw_sgd_step(float* p, const float* g, float* buf, long long n, 
 
 // ---- multi-tensor SGD: one launch updates every parameter of the model -------------------------------------------
 // entries[] (device) is sorted by chunk0; workgroup b finds its tensor by binary search and updates one 16384-element
-// chunk of it with the same arithmetic as sgd_step_kernel.
+// chunk of it with the same arithmetic as sgd_step_kernel.  With lr_table != nullptr the learning rate of an entry is
+// lr_table[entry.lr_slot] (a small device array the host rewrites per step): the entry table itself can then stay
+// constant across steps, which is what a captured hipGraph of the training step needs.
 #define SGD_CHUNK 16384
 __global__ __launch_bounds__(256) void sgd_multi_kernel(const vspw_sgd_entry* __restrict__ entries, int n_entries,
-                                                        float momentum) {
+                                                        float momentum, const float* __restrict__ lr_table) {
     const long long b = blockIdx.x;
     int lo = 0, hi = n_entries - 1;
     while (lo < hi) {
@@ -378,17 +385,11 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const vspw_sgd_entry* __
     float* __restrict__ p = e.p;
     const float* __restrict__ g = e.g;
     float* __restrict__ buf = e.buf;
+    const float lr = (lr_table != nullptr && e.lr_slot >= 0) ? lr_table[e.lr_slot] : e.lr;
     for (long long i = begin + threadIdx.x; i < end; i += blockDim.x) {
         float pv = p[i];
-        const float gv = g[i];
         float bv = e.first ? 0.f : buf[i];
-        bool have = !e.first;
-        for (int r = 0; r < e.mult; ++r) {
-            const float d = gv + e.wd * pv;
-            bv = have ? momentum * bv + d : d;
-            have = true;
-            pv -= e.lr * bv;
-        }
+        sgd_apply(pv, g[i], bv, !e.first, lr, e.wd, momentum, e.mult);
         p[i] = pv;
         buf[i] = bv;
     }
@@ -397,9 +398,9 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const vspw_sgd_entry* __
 extern "C" long long vspw_sgd_chunk_elems(void) { return SGD_CHUNK; }
 
 extern "C" int vspw_sgd_multi(const vspw_sgd_entry* entries, int n_entries, long long total_chunks, float momentum,
-                              void* stream) {
+                              const float* lr_table, void* stream) {
     if (!entries || n_entries <= 0 || total_chunks <= 0 || total_chunks > 0x7fffffffLL) return VSPW_EINVAL;
     hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)total_chunks), dim3(256), 0, vspw_stream(stream), entries,
-                       n_entries, momentum);
+                       n_entries, momentum, lr_table);
     return vspw_launch_status();
 }

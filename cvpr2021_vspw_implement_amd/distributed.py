@@ -40,8 +40,16 @@ def init_from_env(backend=None):
 class GradReducer:
     """Bucketed, backward-overlapped gradient averaging for any nn.Module (device-agnostic host logic)."""
 
-    def __init__(self, module, bucket_mb=25.0, group=None, force=False):
+    def __init__(self, module, bucket_mb=25.0, group=None, force=False, find_unused_parameters=False):
+        """find_unused_parameters=False (default, the contract of torch DDP's default too): every rank produces
+        gradients for the same set of parameters each step - true for the VSPW heads, whose conditional paths
+        (psp_weight, use_memory, clipocr_all) are configuration, not data, dependent.  True: a per-parameter
+        "produced a gradient" flag is reduced with each bucket and read back (one device sync per bucket per step),
+        so a parameter that got a gradient on ANY rank is updated on EVERY rank and one that got none anywhere keeps
+        grad=None."""
         self.group = group
+        self.find_unused = bool(find_unused_parameters)
+        self._flag_cache = {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
         params = [p for p in module.parameters() if p.requires_grad]
@@ -63,9 +71,14 @@ class GradReducer:
         if cur:
             self.buckets.append(cur)
         self.flat, self.slots, self.owner = [], {}, {}
+        self.nelem = []
         for bi, bucket in enumerate(self.buckets):
             n = sum(p.numel() for p in bucket)
-            flat = torch.zeros(n, device=bucket[0].device, dtype=bucket[0].dtype)
+            self.nelem.append(n)
+            # the tail of the buffer carries one "this rank produced a gradient" flag per parameter, reduced with the
+            # gradients: a parameter that got a gradient on ANY rank is updated on EVERY rank (replicas stay equal),
+            # one that got none anywhere keeps grad=None (and is skipped by the optimizer, as in a single process)
+            flat = torch.zeros(n + len(bucket), device=bucket[0].device, dtype=bucket[0].dtype)
             off = 0
             for p in bucket:
                 # a view of the flat buffer with the parameter's own (dense, possibly channels_last) strides
@@ -93,9 +106,17 @@ class GradReducer:
         have = [p for p in bucket if p.grad is not None and p.grad.data_ptr() != self.slots[id(p)].data_ptr()]
         if have:
             torch._foreach_copy_([self.slots[id(p)] for p in have], [p.grad for p in have])
-        for p in bucket:
-            if p.grad is None:
+        n = self.nelem[bi]
+        pattern = tuple(p.grad is not None for p in bucket)
+        for p, present in zip(bucket, pattern):
+            if not present:
                 self.slots[id(p)].zero_()
+        if self.find_unused:
+            cached = self._flag_cache.get(bi)
+            if cached is None or cached[0] != pattern:  # pageable upload only when the pattern changes
+                cached = (pattern, torch.tensor([1.0 if f else 0.0 for f in pattern]).to(self.flat[bi].device))
+                self._flag_cache[bi] = cached
+            self.flat[bi][n:].copy_(cached[1])
         self.handles[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
@@ -114,11 +135,22 @@ class GradReducer:
                 self._launch(bi)
             self.handles[bi].wait()
             self.flat[bi].mul_(inv)
-            for p in bucket:
-                if p.grad is not None:
-                    # the averaged gradient IS the bucket slot (same shape and strides as the parameter): no copy
-                    # back.  The drivers call zero_grad() every step (train_clip2.py:87), which drops these views.
-                    p.grad = self.slots[id(p)]
+            flags = None
+            for j, p in enumerate(bucket):
+                if p.grad is None:
+                    if not self.find_unused:
+                        continue  # contract: no rank produced one either
+                    # no local gradient: take the average anyway if some other rank produced one (reads the reduced
+                    # flags - a device sync, paid only when a local gradient is missing)
+                    if flags is None:
+                        flags = self.flat[bi][self.nelem[bi]:].tolist()
+                    if flags[j] <= 0.0:
+                        continue
+                # the averaged gradient IS the bucket slot (same shape and strides as the parameter): no copy back.
+                # The drivers call zero_grad() every step (train_clip2.py:87), which drops these views; without it
+                # autograd accumulates into the slot in place and the next reduction averages (previous average +
+                # new local gradient), which is still the average of the accumulated gradients.
+                p.grad = self.slots[id(p)]
             self.pending[bi] = len(bucket)
             self.handles[bi] = None
 
@@ -127,10 +159,11 @@ class DataParallelOverRCCL(torch.nn.Module):
     """Drop-in for `nn.DataParallel(module)` + `patch_replication_callback` in the clip drivers: same call
     signature (`module(feed_dict)` -> (loss, acc)), one process per GPU underneath."""
 
-    def __init__(self, module, bucket_mb=25.0, sync_bn=True, force_collectives=False):
+    def __init__(self, module, bucket_mb=25.0, sync_bn=True, force_collectives=False, find_unused_parameters=False):
         super().__init__()
         self.module = module
-        self.reducer = GradReducer(module, bucket_mb, force=force_collectives)
+        self.reducer = GradReducer(module, bucket_mb, force=force_collectives,
+                                   find_unused_parameters=find_unused_parameters)
         self.reducer.broadcast_parameters(module)
         ops.set_sync_bn(sync_bn and self.reducer.active, force=force_collectives)
 

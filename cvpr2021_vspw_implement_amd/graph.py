@@ -1,0 +1,46 @@
+"""hipGraph capture of a static-shape training step.
+
+One TCB-PSP R101 step is ~1 400 kernel launches issued from Python (ctypes + autograd bookkeeping): the host needs
+about as long to enqueue them as the GPU needs to run them.  Shapes, pointers and launch geometry are identical from
+step to step (fixed crop, fixed batch), so the whole step - zero_grad, forward, fused loss, backward, gradient
+all-reduce, SGD - is recorded ONCE into a hipGraph (torch.cuda.CUDAGraph drives hipStreamBeginCapture on ROCm; every
+kernel of libvspw_hip.so is launched on torch's current stream, i.e. the capturing stream) and replayed with one
+hipGraphLaunch per step.
+
+What makes the step capturable:
+  * all device memory comes from torch's caching allocator (graph-private pool during capture); the C ABI never
+    allocates or synchronises;
+  * the inputs live in static tensors that the caller refreshes (`copy_`) before a replay;
+  * the SGD kernel reads its learning rates from a small device array (optim.SGD.set_lrs) and its per-parameter table
+    is uploaded by a memcpy node from pinned memory, so the poly schedule needs no re-capture;
+  * Dropout2d masks come from torch's graph-safe Philox generator (a fresh mask per replay).
+"""
+import torch
+
+
+class GraphedStep(object):
+    """Capture `fn()` after `warmup` eager calls on a side stream; `replay()` re-runs it.  `fn` must be free of host
+    synchronisation (.item(), .cpu(), pageable copies) and must use only static input tensors; whatever it returns
+    (tensors) stays valid and is overwritten by each replay."""
+
+    def __init__(self, fn, warmup=2):
+        if not torch.cuda.is_available():
+            raise RuntimeError("GraphedStep needs a GPU (hipGraph capture)")
+        self.fn = fn
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(int(warmup), 1)):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        # capture on the stream the warm-up ran on: autograd's AccumulateGrad nodes remember the stream they were
+        # created on, and a mismatch with the capturing stream would add cross-stream waits on a non-capturing stream
+        with torch.cuda.graph(self.graph, stream=side):
+            self.outputs = fn()
+        self.stream = side
+
+    def replay(self):
+        self.graph.replay()
+        return self.outputs

@@ -16,6 +16,7 @@ from . import _C
 from ._C import ConvDesc
 
 _vp = ctypes.c_void_p
+_NLL_FIXED = 1048576.0  # VSPW_NLL_FIXED
 
 
 def _stream():
@@ -271,6 +272,7 @@ class BatchNormActFn(torch.autograd.Function):
             if rows * max(_sync_world(), 1) <= 1:
                 raise ValueError("Expected more than 1 value per channel when training, got input size %s"
                                  % (tuple(x.shape),))
+            _infer_fold["gen"] += 1  # running statistics are about to be rewritten in place
             sums = torch.empty((2, c), device=dev, dtype=torch.float64)
             if stat_part is not None:
                 _C.call("vspw_bn_reduce_partials_f32", _p(stat_part), stat_part.shape[0], c, _p(sums), st)
@@ -335,11 +337,20 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, mas
                                 relu, stat_part)
 
 
-_infer_fold = {"enabled": os.environ.get("VSPW_NO_INFER_FOLD", "0") != "1", "cache": {}}
+_infer_fold = {"enabled": os.environ.get("VSPW_NO_INFER_FOLD", "0") != "1", "cache": {}, "gen": 0}
 
 
 def set_inference_folding(enabled):
     _infer_fold["enabled"] = bool(enabled)
+
+
+def invalidate_inference_cache():
+    """Parameters / running statistics were rewritten through raw pointers (the fused SGD step, a training-mode
+    BatchNorm finalize): tensor._version does not see those writes, so the folded conv+BN weights cached for
+    inference are keyed on this generation counter as well."""
+    _infer_fold["gen"] += 1
+    if len(_infer_fold["cache"]) > 4096:
+        _infer_fold["cache"].clear()
 
 
 def _conv_bn_folded(x, w, cbias, gamma, beta, running_mean, running_var, residual, stride, pad, dil, eps, relu):
@@ -351,7 +362,7 @@ def _conv_bn_folded(x, w, cbias, gamma, beta, running_mean, running_var, residua
     if c != x.shape[1]:
         raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (x.shape[1], c))
     srcs = (w, cbias, gamma, beta, running_mean, running_var)
-    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in srcs) + (float(eps),)
+    key = tuple((t.data_ptr(), t._version) if t is not None else None for t in srcs) + (float(eps), _infer_fold["gen"])
     ent = _infer_fold["cache"].get(id(w))
     st = _stream()
     if ent is None or ent[0] != key:
@@ -420,6 +431,7 @@ class ConvBNActFn(torch.autograd.Function):
             if rows * max(_sync_world(), 1) <= 1:
                 raise ValueError("Expected more than 1 value per channel when training, got input size %s"
                                  % (tuple(y.shape),))
+            _infer_fold["gen"] += 1  # running statistics are about to be rewritten in place
             world = _sync_world()
             if part is not None and world == 1:  # single rank: reduce the epilogue partials and finalise in one launch
                 _C.call("vspw_bn_finalize_partials_f32", _p(part), part.shape[0], ctypes.c_double(count), _p(gamma),
@@ -803,7 +815,7 @@ class SegNLLFn(torch.autograd.Function):
         _C.call("vspw_zero_f64", _p(out), 4, st)
         _C.call("vspw_seg_nll_fwd", _p(logp), _p(lab), _p(out), n, h, w, k, H, W, int(ignore_index),
                 1 if want_acc else 0, st)
-        loss = (out[0] / out[1]).float()
+        loss = (out[0] * (1.0 / _NLL_FIXED) / out[1]).float()  # out[0] is fixed-point (include/vspw_hip.h)
         acc = (out[2] / (out[3] + 1e-10)).float()
         ctx.meta = (n, k, h, w, H, W, int(ignore_index), bool(from_logits))
         ctx.save_for_backward(logp, lab, out)

@@ -2,8 +2,9 @@
 
 The reference builds four parameter groups from generators that yield a parameter once per enclosing module
 (models/clip_psp.py:99-135), and torch.optim.SGD (a Python loop in the pinned 1.3.1) then applies the momentum
-update once per occurrence.  This optimizer keeps that behaviour exactly — group['params'] may contain duplicates —
-but folds the k occurrences of a parameter into ONE kernel launch that applies the update k times in registers.
+update once per occurrence, with the weight decay added to p.grad IN PLACE each time.  This optimizer keeps that
+behaviour — group['params'] may contain duplicates — but folds the k occurrences of a parameter into ONE kernel launch
+that applies the update k times in registers.
 """
 import ctypes
 from collections import OrderedDict
@@ -15,10 +16,18 @@ from . import _C
 
 # struct vspw_sgd_entry (include/vspw_hip.h)
 _ENTRY = np.dtype([("p", "<u8"), ("g", "<u8"), ("buf", "<u8"), ("n", "<i8"), ("chunk0", "<i8"), ("lr", "<f4"),
-                   ("wd", "<f4"), ("mult", "<i4"), ("first", "<i4")])
+                   ("wd", "<f4"), ("mult", "<i4"), ("first", "<i4"), ("lr_slot", "<i4"), ("reserved", "<i4")])
 
 
 class SGD(torch.optim.Optimizer):
+    """torch.optim.SGD(momentum, weight_decay) of the pinned PyTorch 1.3.1 (README.md:13), duplicates included: a
+    parameter listed k times in a group is updated k times per step, the weight-decay term accumulating in the
+    gradient across the k applications (1.3.1 adds it in place: d_p.add_(weight_decay, p.data)).
+
+    State layout differs from torch's in one way: group['params'] is de-duplicated and the multiplicities are kept in
+    group['mult'], so `opt_epoch_N.pth` files are NOT interchangeable with the reference's optimizer checkpoints
+    (model checkpoints are)."""
+
     def __init__(self, params, lr=0.02, momentum=0.0, weight_decay=0.0):
         defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay)
         groups = []
@@ -33,18 +42,19 @@ class SGD(torch.optim.Optimizer):
             g["mult"] = list(mult.values())
             groups.append(g)
         super().__init__(groups, defaults)
+        self._table_key = None
+        self._table = None
+        self._lr_dev = None
+        self._lr_host = None
+        self._graph_keepalive = []
+        self._pinned = None
 
-    @torch.no_grad()
-    def step(self, closure=None):
-        """One multi-tensor launch (vspw_sgd_multi) updates every parameter; per-parameter records (pointers, size,
-        lr, weight decay, multiplicity) are rebuilt each step because autograd hands out fresh gradient tensors."""
-        loss = None
-        if closure is not None:
-            with torch.enable_grad():
-                loss = closure()
+    def _collect(self):
+        """[(momentum, device) -> [(p, g, buf, lr_slot, wd, mult)]]; momentum buffers are created zero-filled, which
+        makes `buf = momentum*0 + g` on the first step exactly torch's `buf = clone(g)`."""
         by_mom = {}
-        for group in self.param_groups:
-            lr, wd, mom = float(group["lr"]), float(group["weight_decay"]), float(group["momentum"])
+        for gi, group in enumerate(self.param_groups):
+            wd, mom = float(group["weight_decay"]), float(group["momentum"])
             for p, mult in zip(group["params"], group["mult"]):
                 if p.grad is None:
                     continue
@@ -54,23 +64,76 @@ class SGD(torch.optim.Optimizer):
                 if g.stride() != p.stride():
                     g = torch.empty_like(p).copy_(g)
                 st = self.state[p]
-                first = "momentum_buffer" not in st
-                if first:
-                    st["momentum_buffer"] = torch.empty_like(p)
-                by_mom.setdefault((mom, p.device), []).append((p, g, st["momentum_buffer"], lr, wd, int(mult), first))
+                if "momentum_buffer" not in st:
+                    st["momentum_buffer"] = torch.zeros_like(p)
+                by_mom.setdefault((mom, p.device), []).append((p, g, st["momentum_buffer"], gi, wd, int(mult)))
+        return by_mom
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        """One multi-tensor launch (vspw_sgd_multi) updates every parameter.  The per-parameter records (pointers,
+        size, weight decay, multiplicity, learning-rate slot) are kept on the device and only re-uploaded when a
+        pointer changed (autograd hands out fresh gradient tensors in eager mode; under a captured hipGraph they are
+        constant); learning rates travel separately through a [n_groups] device array."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        by_mom = self._collect()
+        if not by_mom:
+            return loss
         chunk = int(_C.query("vspw_sgd_chunk_elems"))
+        capturing = torch.cuda.is_current_stream_capturing()
+        lrs = np.asarray([float(g["lr"]) for g in self.param_groups], dtype=np.float32)
         for (mom, dev), items in by_mom.items():
+            if self._lr_dev is None or self._lr_dev.device != dev or self._lr_dev.numel() != lrs.size:
+                self._lr_dev = torch.zeros(lrs.size, device=dev, dtype=torch.float32)
+                self._lr_host = None
+            if not capturing and (self._lr_host is None or not np.array_equal(self._lr_host, lrs)):
+                # pageable -> device copy: the host buffer is consumed before the call returns (no race with the next
+                # step's schedule update); under capture the caller refreshes the array with set_lrs() before replay
+                self._lr_dev.copy_(torch.from_numpy(lrs.copy()))
+                self._lr_host = lrs.copy()
             rec = np.zeros(len(items), dtype=_ENTRY)
             c0 = 0
-            for i, (p, g, buf, lr, wd, mult, first) in enumerate(items):
+            for i, (p, g, buf, slot, wd, mult) in enumerate(items):
                 n = p.numel()
-                rec[i] = (p.data_ptr(), g.data_ptr(), buf.data_ptr(), n, c0, lr, wd, mult, 1 if first else 0)
+                rec[i] = (p.data_ptr(), g.data_ptr(), buf.data_ptr(), n, c0, 0.0, wd, mult, 0, slot, 0)
                 c0 += (n + chunk - 1) // chunk
-            table = torch.from_numpy(rec.view(np.uint8)).to(dev, non_blocking=True)
-            _C.call("vspw_sgd_multi", ctypes.c_void_p(table.data_ptr()), len(items), c0, mom,
+            key = (mom, dev, rec.tobytes())
+            if self._table_key != key:
+                host = torch.from_numpy(rec.view(np.uint8).copy())
+                if capturing:
+                    # a memcpy node needs a source that outlives the graph: a pinned staging buffer that was allocated
+                    # by an earlier eager step (hipHostMalloc is not allowed while a stream is capturing)
+                    if self._pinned is None or self._pinned.numel() != host.numel():
+                        raise RuntimeError("vspw SGD: run at least one eager step before capturing a hipGraph")
+                    self._pinned.copy_(host)
+                    self._table = torch.empty(host.numel(), device=dev, dtype=torch.uint8)
+                    self._table.copy_(self._pinned, non_blocking=True)
+                    self._graph_keepalive.append((self._pinned, self._table))
+                    self._pinned = None  # owned by the graph from now on; a later capture stages through a new one
+                else:
+                    if self._pinned is None or self._pinned.numel() != host.numel():
+                        self._pinned = torch.empty(host.numel(), dtype=torch.uint8).pin_memory()
+                    self._table = host.to(dev)
+                self._table_key = key
+            _C.call("vspw_sgd_multi", ctypes.c_void_p(self._table.data_ptr()), len(items), c0, mom,
+                    ctypes.c_void_p(self._lr_dev.data_ptr()),
                     ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
-            self._keepalive = (table, items)  # until the next step: the launch is asynchronous
+            self._keepalive = items  # until the next step: the launch is asynchronous
+        from . import ops
+
+        ops.invalidate_inference_cache()  # folded conv+BN weights derive from the parameters just rewritten
         return loss
+
+    def set_lrs(self):
+        """Upload the groups' current learning rates (call before replaying a captured step)."""
+        if self._lr_dev is not None:
+            lrs = np.asarray([float(g["lr"]) for g in self.param_groups], dtype=np.float32)
+            if self._lr_host is None or not np.array_equal(self._lr_host, lrs):
+                self._lr_dev.copy_(torch.from_numpy(lrs.copy()))
+                self._lr_host = lrs.copy()
 
 
 def create_optimizers(model, lr, weight_decay=1e-4, momentum=0.9, fix=False):

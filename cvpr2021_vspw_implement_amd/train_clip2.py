@@ -121,14 +121,17 @@ def train(segmentation_module, data_loader, optimizers, history, epoch, cfg, arg
         history["train"]["acc"].append(acc.data.item())
 
 
-def test(segmentation_module, args, transform, log=print):
-    """Validation pass of train_clip2.py:126-172 (every 15th frame of the `val` videos)."""
+def test(segmentation_module, args, transform, log=print, rank=0, world=1):
+    """Validation pass of train_clip2.py:126-172 (every 15th frame of the `val` videos).  With world > 1 the videos
+    are sharded round-robin over the ranks and the confusion matrices summed (one all-reduce): every rank takes part,
+    so no rank sits in a collective of the next epoch while rank 0 validates alone (RCCL watchdog), and the metrics
+    are those of the whole split (confusion matrices add)."""
     segmentation_module.eval()
     evaluator = Evaluator(args.num_class)
     log("validation")
     with open(os.path.join(args.dataroot, "val.txt"), "r") as f:
         videolists = [line[:-1] for line in f.readlines()]
-    for video in videolists:
+    for video in videolists[rank::world]:
         test_dataset = TestDataset_clip(args.dataroot, video, args, is_train=True)
         loader = torch.utils.data.DataLoader(test_dataset, batch_size=1, shuffle=False, num_workers=args.workers,
                                              drop_last=False, collate_fn=collate_raw)
@@ -142,6 +145,11 @@ def test(segmentation_module, args, transform, log=print):
                 pred = torch.argmax(scores, dim=1).data.cpu().numpy()
                 target = gts.squeeze(1).cpu().numpy()
                 evaluator.add_batch(target, pred)
+    if world > 1:
+        cm = torch.from_numpy(evaluator.confusion_matrix).to(transform.device if hasattr(transform, "device")
+                                                             else "cuda")
+        vdist.dist.all_reduce(cm)
+        evaluator.confusion_matrix = cm.cpu().numpy()
     Acc = evaluator.Pixel_Accuracy()
     Acc_class = evaluator.Pixel_Accuracy_Class()
     mIoU = evaluator.Mean_Intersection_over_Union()
@@ -232,9 +240,9 @@ def main(cfg, gpus, args):
         train(segmentation_module, loader_train, optimizer, history, epoch + 1, cfg, args, transform, log)
         if (epoch + 1) % args.ckpt_every == 0:
             checkpoint(optimizer, segmentation_module, history, args, epoch + 1)
-            if args.validation and rank == 0:
+            if args.validation:
                 test(segmentation_module.module if hasattr(segmentation_module, "module") else segmentation_module,
-                     args, transform, log)
+                     args, transform, log, rank, world)
     log("Training Done!")
     return history
 

@@ -29,7 +29,7 @@ extern "C" {
 #define VSPW_EINVAL (-1)  /* bad argument / geometry / workspace too small */
 #define VSPW_ELAUNCH (-2) /* hipLaunchKernel reported an error */
 
-#define VSPW_ABI_VERSION 1
+#define VSPW_ABI_VERSION 2
 int vspw_abi_version(void);
 /* The hipError_t behind the most recent VSPW_ELAUNCH (0 if none) - for error messages. */
 int vspw_last_hip_error(void);
@@ -197,8 +197,11 @@ int vspw_softmax_pixels_bwd(const float* dy, const float* y, float* dx, int b, i
                             void* stream);
 /* Fused  F.interpolate(logp,(H,W),bilinear) -> NLLLoss(ignore_index) -> pixel_acc  of models/clip_psp.py:198-216,
  * models/models.py:92-107.  logp [n][h][w][k] are log-probabilities at feature resolution; label [n][H][W] int64.
- * out[0]=sum of -logp_up[label] over non-ignored pixels, out[1]=#non-ignored, out[2]=#(argmax==label), out[3]=#(label>=0)
- * (fp64).  out must be zeroed by the caller (vspw_zero_f64). */
+ * out[0]=VSPW_NLL_FIXED * sum of -logp_up[label] over non-ignored pixels (each workgroup's partial sum is rounded to a
+ * multiple of 1/VSPW_NLL_FIXED, so the fp64 atomic accumulation adds integers and is bit-reproducible whatever the
+ * order), out[1]=#non-ignored, out[2]=#(argmax==label), out[3]=#(label>=0) (fp64).  loss = out[0]/VSPW_NLL_FIXED/out[1].
+ * out must be zeroed by the caller (vspw_zero_f64). */
+#define VSPW_NLL_FIXED 1048576.0
 int vspw_seg_nll_fwd(const float* logp, const int64_t* label, double* out, int n, int h, int w, int k, int H, int W,
                      int ignore_index, int want_acc, void* stream);
 /* Gathers the bilinear adjoint of -gscale/count at the label channel into d(loss)/d(logp) [n][h][w][k]; with
@@ -283,13 +286,17 @@ int vspw_frame_transform(const uint8_t* img, const uint8_t* lab, int h, int w, i
                          int crop_y, int crop_x, int out_h, int out_w, const float* mean3, const float* std3,
                          float* img_out, float* lab_out, void* stream);
 
-/* torch.optim.SGD(momentum, weight_decay) update applied `mult` times with the same gradient (the reference's
+/* torch.optim.SGD(momentum, weight_decay) update applied `mult` times in a row, weight decay accumulating
+ * in the gradient across the applications as in the pinned PyTorch 1.3.1 (in-place d_p.add_(wd, p)) (the reference's
  * parameter-group generators yield a parameter once per enclosing module, train_clip2.py:215-236 +
  * models/clip_psp.py:99-135).  p, g, buf are dense tensors with identical strides; first != 0 initialises buf. */
 int vspw_sgd_step(float* p, const float* g, float* buf, long long n, float lr, float wd, float momentum, int mult,
                   int first, void* stream);
 /* The same update for EVERY parameter in one launch.  `entries` is a DEVICE array of n_entries records sorted by
- * chunk0 (chunk0 = number of vspw_sgd_chunk_elems()-sized chunks of all preceding tensors); total_chunks = grid size. */
+ * chunk0 (chunk0 = number of vspw_sgd_chunk_elems()-sized chunks of all preceding tensors); total_chunks = grid size.
+ * lr_table (device, may be NULL): when given, an entry with lr_slot >= 0 takes its learning rate from
+ * lr_table[lr_slot] instead of entry.lr - the poly schedule of train_clip2.py:239-252 then only rewrites that small
+ * array and the entry table stays constant across steps (needed by a captured hipGraph of the training step). */
 typedef struct vspw_sgd_entry {
     float* p;
     const float* g;
@@ -298,10 +305,11 @@ typedef struct vspw_sgd_entry {
     long long chunk0;
     float lr, wd;
     int mult, first;
+    int lr_slot, reserved;
 } vspw_sgd_entry;
 long long vspw_sgd_chunk_elems(void);
 int vspw_sgd_multi(const vspw_sgd_entry* entries, int n_entries, long long total_chunks, float momentum,
-                   void* stream);
+                   const float* lr_table, void* stream);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,57 @@ def test_grad_reducer_world2_gloo(bucket_mb):
         assert res[0] > 1, "small bucket cap must split the parameters into several buckets"
 
 
+class _BranchNet(torch.nn.Module):
+    """`extra` is used on rank 0 only (a conditional branch such as psp_weight / use_memory); `never` on no rank."""
+
+    def __init__(self):
+        super().__init__()
+        self.fc = torch.nn.Linear(4, 2)
+        self.extra = torch.nn.Linear(4, 2)
+        self.never = torch.nn.Linear(4, 2)
+
+    def forward(self, x, use_extra):
+        y = self.fc(x)
+        if use_extra:
+            y = y + self.extra(x)
+        return y.pow(2).mean()
+
+
+def _branch_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from cvpr2021_vspw_implement_amd import distributed as vdist
+
+    vdist.init_from_env(backend="gloo")
+    torch.manual_seed(5)
+    net = _BranchNet()
+    wrapped = vdist.DataParallelOverRCCL(net, sync_bn=False, find_unused_parameters=True)
+    x = torch.randn(3, 4, generator=torch.Generator().manual_seed(11 + rank))
+    net.zero_grad()
+    wrapped(x, rank == 0).backward()
+    wrapped.finish_gradients()
+    assert net.never.weight.grad is None, "a parameter without gradient on every rank must stay grad=None"
+    assert net.extra.weight.grad is not None, "a gradient produced on one rank must reach every rank"
+    q.put((rank, net.extra.weight.grad.clone(), net.fc.weight.grad.clone()))
+    dist.destroy_process_group()
+
+
+def test_grad_on_one_rank_only_reaches_all_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_branch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=170) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res = {r: (e, f) for r, e, f in got}
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "replicas must see equal gradients"
+    assert res[0][0].abs().sum() > 0
+
+
 def test_single_process_is_passthrough():
     from cvpr2021_vspw_implement_amd import distributed as vdist
 

@@ -419,8 +419,9 @@ def test_sgd_matches_loop_semantics_with_duplicate_params(dev):
         for i, p in enumerate(ref):
             this_wd = wd if i % 2 == 0 else 0.0
             this_lr = lr * (0.1 if i < 2 else 1.0)
-            for _ in range(mults[i]):
-                d = grads[step][i] + this_wd * p
+            d = grads[step][i].clone()  # torch 1.3.1: d_p = p.grad.data, then d_p.add_(weight_decay, p.data) IN PLACE,
+            for _ in range(mults[i]):   # so the decay term accumulates over the duplicate occurrences of a parameter
+                d += this_wd * p
                 bufs[i] = d.clone() if bufs[i] is None else bufs[i] * mom + d
                 p -= this_lr * bufs[i]
 

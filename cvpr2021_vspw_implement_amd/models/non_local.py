@@ -1,8 +1,9 @@
 """Non-local block (mode 'dot') on the HIP kernels, mirroring reference models/non_local.py:7-151.
 
-f = theta^T phi / N has no softmax, so y = f g is evaluated as two MFMA GEMMs over the [B, N, C] pixel-row matrices
-that NHWC memory provides for free (N = H*W, or T*H*W for the spatio-temporal block).  The 1/N is applied to g
-(N x 128) instead of f (N x N): same value up to fp32 rounding, N/128 times less traffic.
+y = (theta^T phi / N) g is evaluated by ONE fused kernel (csrc/nonlocal.hip, ops.non_local_dot) over the [B, N, C]
+pixel-row matrices that NHWC memory provides for free (N = H*W, or T*H*W for the spatio-temporal block): 32-key tiles of
+phi / g stream through LDS, the affinity tile lives in MFMA accumulators and feeds the second product directly, so the
+N x N affinity (2.5 GB per sample at T = 7) never exists in memory - forward or backward.
 """
 import torch.nn as nn
 
@@ -53,9 +54,14 @@ class NLBlockND(nn.Module):
         g = ops.pixels_view(ops.conv2d(xr, self._w2d(self.g), self.g.bias))  # [B,N,Ci]
         th = ops.pixels_view(ops.conv2d(xr, self._w2d(self.theta), self.theta.bias))
         ph = ops.pixels_view(ops.conv2d(xr, self._w2d(self.phi), self.phi.bias))
-        f = ops.bmm_nt(th, ph)  # [B,N,N]
-        gT = ops.transpose_last2(ops.scale(g, 1.0 / n_pos))  # [B,Ci,N]
-        y = ops.from_pixels(ops.bmm_nt(f, gT), n_pos, 1)  # [B,Ci,N,1]
+        if ops.nl_dot_supported(self.inter_channels):
+            # fused: theta phi^T is streamed through registers, never written (csrc/nonlocal.hip); f / N happens on the
+            # affinity tile, where the reference applies it
+            y = ops.from_pixels(ops.non_local_dot(th, ph, g, 1.0 / n_pos), n_pos, 1)  # [B,Ci,N,1]
+        else:  # other channel counts: two dense GEMMs over a materialised [B,N,N] affinity
+            f = ops.bmm_nt(th, ph)  # [B,N,N]
+            gT = ops.transpose_last2(ops.scale(g, 1.0 / n_pos))  # [B,Ci,N]
+            y = ops.from_pixels(ops.bmm_nt(f, gT), n_pos, 1)  # [B,Ci,N,1]
         wz, bnz = self.W_z[0], self.W_z[1]
         z = ops.conv_bn_act(y, self._w2d(wz), wz.bias, bnz.weight, bnz.bias, bnz.running_mean, bnz.running_var,
                             residual=xr, mask=None, stride=1, pad=0, dil=1, training=bnz.training,

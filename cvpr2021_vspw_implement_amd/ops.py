@@ -937,6 +937,51 @@ def bmm_tn(a, b):
     return BmmTNFn.apply(a, b)
 
 
+def _nl_dot(q, k, v, scale):
+    """scale * (q k^T) v for contiguous [B,N,C] operands, without the N x N intermediate (csrc/nonlocal.hip)."""
+    B, N, C = q.shape
+    out = torch.empty((B, N, C), device=q.device, dtype=torch.float32)
+    nbytes = _C.query("vspw_nl_dot_workspace", B, N, C)
+    ws = _ws(nbytes, q.device) if nbytes else None
+    with _Timed("nl_dot_kernel", 4.0 * B * N * N * C, "nl_dot b%d n%d c%d" % (B, N, C)):
+        _C.call("vspw_nl_dot", _p(q), _p(k), _p(v), _p(out), B, N, C, float(scale), _p(ws), nbytes, _stream())
+    return out
+
+
+def nl_dot_supported(c):
+    return c in (32, 64, 128)
+
+
+class NonLocalDotFn(torch.autograd.Function):
+    """y = (theta phi^T / N) g of NLBlockND mode 'dot' (reference models/non_local.py:116-133), theta/phi/g [B,N,C]:
+    the affinity f = theta phi^T is streamed through registers tile by tile and never written to memory; the three
+    gradients are the same kernel with the operands permuted (f is linear in everything: no softmax)."""
+
+    @staticmethod
+    def forward(ctx, theta, phi, g, scale):
+        _require_gpu(theta, "non_local_dot")
+        theta, phi, g = theta.contiguous(), phi.contiguous(), g.contiguous()
+        if theta.shape != phi.shape or theta.shape != g.shape or theta.dim() != 3:
+            raise RuntimeError("non_local_dot: theta, phi, g must be [B,N,C] of equal shape")
+        ctx.scale = float(scale)
+        ctx.save_for_backward(theta, phi, g)
+        return _nl_dot(theta, phi, g, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        theta, phi, g = ctx.saved_tensors
+        dy = dy.contiguous()
+        s = ctx.scale
+        dth = _nl_dot(dy, g, phi, s) if ctx.needs_input_grad[0] else None   # (dy g^T) phi
+        dph = _nl_dot(g, dy, theta, s) if ctx.needs_input_grad[1] else None  # (g dy^T) theta
+        dg = _nl_dot(phi, theta, dy, s) if ctx.needs_input_grad[2] else None  # (phi theta^T) dy
+        return dth, dph, dg, None
+
+
+def non_local_dot(theta, phi, g, scale):
+    return NonLocalDotFn.apply(theta, phi, g, scale)
+
+
 class TransposeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a):

@@ -159,7 +159,7 @@ def main(cfg, gpu, args, log=print):
     log("Video Consistency num :{} acc:{}".format(args.vc_clip_num, VC_Acc))
     log("Inference done!")
     return {"Acc": Acc, "Acc_class": Acc_class, "mIoU": mIoU, "fwIoU": FWIoU, "video_mIoU": total_vmIOU,
-            "video_fwIoU": total_vfwIOU, "VC": VC_Acc}
+            "video_fwIoU": total_vfwIOU, "VC": VC_Acc, "confusion_matrix": evaluator.confusion_matrix.copy()}
 
 
 def build_parser():
@@ -192,7 +192,9 @@ def build_parser():
     p.add_argument("--distnearest", type=str2bool, default=False)
     p.add_argument("--temp", type=float, default=3)
     p.add_argument("--max_distances", type=str, default="10")
-    p.add_argument("--method", type=str, default="", choices=METHODS)
+    p.add_argument("--method", type=str, default="",  # the reference lists the same methods in this order here
+                   choices=["tdnet", "ETC", "nonlocal3d", "netwarp"] + [m for m in METHODS if m not in
+                                                                       ("tdnet", "ETC", "nonlocal3d", "netwarp")])
     p.add_argument("--clipocr_all", type=str2bool, default=False)
     p.add_argument("--dilation2", type=str, default="2,5,9")
     p.add_argument("--use_memory", type=str2bool, default=False)

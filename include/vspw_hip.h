@@ -311,6 +311,18 @@ long long vspw_sgd_chunk_elems(void);
 int vspw_sgd_multi(const vspw_sgd_entry* entries, int n_entries, long long total_chunks, float momentum,
                    const float* lr_table, void* stream);
 
+/* ---------------------------------------------------------------- non-local affinity (nonlocal.hip) ---- */
+/* out[b][i][:] = scale * sum_j (q[b][i][:] . k[b][j][:]) * v[b][j][:]   for q, k, v, out [b][n][c] (pixel rows x channels,
+ * i.e. the [B,N,C] matrices NLBlockND's view/permute chains produce, zero-copy from NHWC memory), c in {32, 64, 128}.
+ * Replaces  f = matmul(theta_x, phi_x); f_div_C = f / N; y = matmul(f_div_C, g_x)  of models/non_local.py:116-133
+ * (mode 'dot', used by Non_local2d / Non_local3d, models/non_local_models.py:19-72,124-151) without materialising the
+ * n x n affinity: y = nl(theta, phi, g; 1/N).  The same entry point evaluates the three gradients
+ * (d theta = nl(dy, g, phi), d g = nl(phi, theta, dy), d phi = nl(g, dy, theta)).  ws: vspw_nl_dot_workspace() bytes
+ * (per-key-chunk partial outputs, summed in chunk order: deterministic). */
+size_t vspw_nl_dot_workspace(int b, int n, int c);
+int vspw_nl_dot(const float* q, const float* k, const float* v, float* out, int b, int n, int c, float scale, void* ws,
+                size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -574,6 +574,285 @@ def case_keys(M, tag="state_keys"):
     print(tag, "done")
 
 
+class _YacsNode(dict):
+    """Minimal stand-in for yacs.config.CfgNode (yacs is not installed here): attribute access + the two merge calls the
+    reference's drivers make.  Only used to EXECUTE the reference's config/defaults.py and driver files."""
+
+    def __init__(self, init=None, **kw):
+        super().__init__()
+        for k, v in (init or {}).items():
+            self[k] = v
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+    def merge_from_file(self, f):
+        import yaml
+
+        def rec(dst, src):
+            for k, v in src.items():
+                if isinstance(v, dict):
+                    rec(dst[k], v)
+                else:
+                    dst[k] = tuple(v) if isinstance(v, list) else v
+
+        rec(self, yaml.safe_load(open(f)))
+
+    def merge_from_list(self, lst):
+        pass
+
+    def clone(self):
+        import copy
+
+        return copy.deepcopy(self)
+
+
+def import_reference_drivers():
+    """train_clip2 / test_clip2 of the reference as modules (functions only; their __main__ blocks are not run)."""
+    import importlib.util
+
+    y, yc = types.ModuleType("yacs"), types.ModuleType("yacs.config")
+    yc.CfgNode = _YacsNode
+    y.config = yc
+    sys.modules["yacs"], sys.modules["yacs.config"] = y, yc
+    # `utils` already resolves to RAFT_core/utils (a package) for the RAFT imports: bind the reference's utils.py
+    spec = importlib.util.spec_from_file_location("utils", os.path.join(REF, "utils.py"))
+    um = importlib.util.module_from_spec(spec)
+    sys.modules["utils"] = um
+    spec.loader.exec_module(um)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import test_clip2 as ref_test  # noqa
+        import train_clip2 as ref_train  # noqa
+    finally:
+        os.chdir(cwd)
+    return ref_train, ref_test, um
+
+
+def _parser_defaults(path):
+    """Run the `__main__` block of a reference driver up to parse_args() and return {flag: (default, type, choices)}.
+    parse_args is replaced by a hook that records the parser and aborts, so nothing after it executes."""
+    import argparse
+    import runpy
+
+    class _Stop(Exception):
+        pass
+
+    got = {}
+    orig = argparse.ArgumentParser.parse_args
+
+    def hook(self, *a, **k):
+        for act in self._actions:
+            if act.dest == "help":
+                continue
+            tname = getattr(act.type, "__name__", str(act.type)) if act.type is not None else "None"
+            got[act.dest] = (repr(act.default), tname, repr(list(act.choices)) if act.choices else "None",
+                             "opt" if act.option_strings else "pos")
+        raise _Stop()
+
+    argparse.ArgumentParser.parse_args = hook
+    cwd, argv = os.getcwd(), sys.argv
+    os.chdir(REF)
+    sys.argv = [path]
+    try:
+        runpy.run_path(os.path.join(REF, path), run_name="__main__")
+    except _Stop:
+        pass
+    finally:
+        argparse.ArgumentParser.parse_args = orig
+        os.chdir(cwd)
+        sys.argv = argv
+    return got
+
+
+def case_drivers(M, tag="drivers_reference"):
+    """The host-side row of SURVEY.md 8(f)-2 pinned on the reference itself: Evaluator (utils.py:55-107), get_common
+    (utils.py:37-53), parse_devices, create_optimizers / adjust_learning_rate (train_clip2.py:215-252), the argparse
+    flags and defaults of both drivers (train_clip2.py:404-490, test_clip2.py:349-406), config/defaults.py and the
+    palette of test_clip2.py:25."""
+    ref_train, ref_test, ref_utils = import_reference_drivers()
+    res = {}
+    rng = np.random.RandomState(304)
+    # ---- config defaults (captured first: the optimizer section below writes schedule fields into cfg)
+    # ---- config defaults (config/defaults.py executed with the CfgNode stand-in) and the 18 yaml files
+    flat = []
+
+    def rec(prefix, node):
+        for k in node:
+            if isinstance(node[k], dict):
+                rec(prefix + k + ".", node[k])
+            else:
+                flat.append((prefix + k, repr(node[k])))
+
+    import importlib
+
+    cfgmod = importlib.import_module("config.defaults")
+    rec("", cfgmod._C)
+    res["cfg:keys"] = np.array([k for k, _ in flat])
+    res["cfg:values"] = np.array([v for _, v in flat])
+
+    # ---- Evaluator: 124 classes, several absent from the ground truth, 255 = ignore, predictions over all classes
+    for name, ncls, present in (("ev124", 124, [0, 1, 2, 5, 8, 13, 21, 34, 55, 89, 123]), ("ev7", 7, [0, 2, 3, 6])):
+        ev = ref_utils.Evaluator(ncls)
+        gts, prs = [], []
+        for b in range(3):
+            gt = rng.choice(present + [255], size=(2, 37, 41)).astype(np.float32)
+            pr = np.where(rng.rand(2, 37, 41) < 0.6, np.minimum(gt, ncls - 1), rng.randint(0, ncls, (2, 37, 41)))
+            pr = pr.astype(np.int64)
+            gts.append(gt)
+            prs.append(pr)
+            ev.add_batch(gt, pr)
+        res[name + ":gt"] = np.stack(gts)
+        res[name + ":pred"] = np.stack(prs)
+        res[name + ":cm"] = ev.confusion_matrix.copy()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            res[name + ":metrics"] = np.array([ev.Pixel_Accuracy(), ev.Pixel_Accuracy_Class(),
+                                               ev.Mean_Intersection_over_Union(),
+                                               ev.Frequency_Weighted_Intersection_over_Union()], dtype=np.float64)
+            ev.beforeval()
+            res[name + ":cm_beforeval"] = ev.confusion_matrix.copy()
+            res[name + ":metrics_beforeval"] = np.array([ev.Pixel_Accuracy(), ev.Pixel_Accuracy_Class(),
+                                                         ev.Mean_Intersection_over_Union(),
+                                                         ev.Frequency_Weighted_Intersection_over_Union()],
+                                                        dtype=np.float64)
+        ev.reset()
+        res[name + ":cm_reset_sum"] = np.float64(ev.confusion_matrix.sum())
+    # ---- video consistency
+    h, w = 19, 23
+    base_gt = rng.randint(0, 5, (h, w))
+    gl, pl = [], []
+    for t in range(14):
+        g = base_gt.copy()
+        flip = rng.rand(h, w) < 0.05 * (t % 4)
+        g[flip] = rng.randint(0, 5, flip.sum())
+        p = g.copy()
+        noise = rng.rand(h, w) < 0.15
+        p[noise] = rng.randint(0, 5, noise.sum())
+        gl.append(g)
+        pl.append(p)
+    res["vc:gt"] = np.stack(gl)
+    res["vc:pred"] = np.stack(pl)
+    for cn in (2, 4, 8):
+        res["vc:accs%d" % cn] = np.array(ref_utils.get_common(gl, pl, cn, h, w), dtype=np.float64)
+    # ---- parse_devices
+    devs = ["0-3", "0,1,2,3", "gpu0-gpu2", "2", "0,2-3", "3-1"]
+    res["parse_devices:in"] = np.array(devs)
+    res["parse_devices:out"] = np.array([",".join(ref_utils.parse_devices(d)) for d in devs])
+    # ---- optimizer groups + poly schedule on the reference's Clip_PSP
+    enc = M.ModelBuilder.build_encoder(arch="resnet50dilated", fc_dim=2048)
+    mod = M.Clip_PSP(enc, torch.nn.NLLLoss(ignore_index=255), args_ns(), deep_sup_scale=0.4)
+    cfg = ref_train.cfg
+    for fix in (False, True):
+        a = types.SimpleNamespace(lr=0.002, fix=fix)
+        cfg.TRAIN.weight_decay = 1e-4
+        opt = ref_train.create_optimizers(mod, cfg, a)
+        res["opt:fix%d:group_sizes" % fix] = np.array([len(g["params"]) for g in opt.param_groups])
+        res["opt:fix%d:group_wd" % fix] = np.array([g["weight_decay"] for g in opt.param_groups], dtype=np.float64)
+        res["opt:fix%d:group_lr0" % fix] = np.array([g["lr"] for g in opt.param_groups], dtype=np.float64)
+        res["opt:fix%d:momentum" % fix] = np.float64(opt.param_groups[0]["momentum"])
+        max_iters = 1200
+        iters = [0, 1, 7, 300, 599, 1100, 1199]
+        trace, running = [], []
+        for it in iters:
+            ref_train.adjust_learning_rate(opt, it, cfg, max_iters, a)
+            trace.append([g["lr"] for g in opt.param_groups])
+            running.append(cfg.TRAIN.running_lr_encoder)
+        res["lr:fix%d:iters" % fix] = np.array(iters)
+        res["lr:fix%d:max_iters" % fix] = np.int64(max_iters)
+        res["lr:fix%d:trace" % fix] = np.array(trace, dtype=np.float64)
+        res["lr:fix%d:running_lr_encoder" % fix] = np.array(running, dtype=np.float64)
+    # ---- argparse surfaces
+    for drv in ("train_clip2.py", "test_clip2.py"):
+        d = _parser_defaults(drv)
+        keys = sorted(d)
+        res["argparse:%s:dest" % drv] = np.array(keys)
+        res["argparse:%s:default" % drv] = np.array([d[k][0] for k in keys])
+        res["argparse:%s:type" % drv] = np.array([d[k][1] for k in keys])
+        res["argparse:%s:choices" % drv] = np.array([d[k][2] for k in keys])
+        res["argparse:%s:kind" % drv] = np.array([d[k][3] for k in keys])
+    import yaml
+
+    ynames, yflat = [], []
+    cdir = os.path.join(REF, "config")
+    for f in sorted(os.listdir(cdir)):
+        if f.endswith(".yaml"):
+            y = yaml.safe_load(open(os.path.join(cdir, f)))
+            ynames.append(f)
+            yflat.append(repr(sorted((sec + "." + k, repr(v)) for sec, d in y.items() if isinstance(d, dict)
+                                     for k, v in d.items()) + sorted((k, repr(v)) for k, v in y.items()
+                                                                     if not isinstance(v, dict))))
+    res["yaml:names"] = np.array(ynames)
+    res["yaml:flat"] = np.array(yflat)
+    res["palette"] = np.array(ref_test._palette, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, len(res), "arrays")
+
+
+FIXBN_FULL = ("encoder.conv1.weight", "encoder.layer1.0.conv2.weight", "encoder.layer2.0.downsample.0.weight",
+              "encoder.layer3.5.conv2.bias")
+
+
+def case_fixbn(M, method, arch, tag, T=3, train_shape=(2, 3, 65, 65)):
+    """Training step with frozen BatchNorm (cfg.TRAIN.fix_bn: train_clip2.py `segmentation_module.train(not
+    cfg.TRAIN.fix_bn)`, config/defaults.py:71): the module is in eval mode - running statistics, no dropout - while the
+    loss and its gradients are computed.  Without batch statistics the gradients are smooth functions of the weights,
+    so they can be gated element-wise; stored in fp32 and from the float64 re-run."""
+    torch.manual_seed(0)
+    enc = M.ModelBuilder.build_encoder(arch=arch, fc_dim=2048)
+    crit = torch.nn.NLLLoss(ignore_index=255)
+    cls = {"clip_psp": M.Clip_PSP, "clip_ocr": M.ClipOCRNet}[method]
+    mod = cls(enc, crit, args_ns(), deep_sup_scale=0.4)
+    load_det(mod)
+    imgs = [torch.from_numpy(det_input("%s:train:%d" % (tag, t), train_shape)) for t in range(T)]
+    labs = [torch.from_numpy(det_labels("%s:train:%d" % (tag, t), (train_shape[0], 1) + train_shape[2:], K))
+            for t in range(T)]
+
+    def feed(cast=lambda x: x):
+        return {"img_data": cast(imgs[-1]), "seg_label": cast(labs[-1]), "clipimgs_data": [cast(i) for i in imgs[:-1]],
+                "cliplabels_data": [cast(l) for l in labs[:-1]]}
+
+    res = calibrate_bn(mod, lambda: mod(feed()))
+    calibrated_sd = {k: v.clone() for k, v in mod.state_dict().items()}
+    bn_params = [k for k, _ in mod.named_parameters() if ".bn" in k or ".downsample.1." in k]
+    full = tuple(FIXBN_FULL) + tuple(bn_params)
+
+    def run(store_suffix):
+        mod.eval()  # = segmentation_module.train(not fix_bn) with fix_bn True
+        mod.zero_grad()
+        loss, acc = mod(feed((lambda x: x.double()) if store_suffix else (lambda x: x)))
+        loss.backward()
+        res["train_loss" + store_suffix] = np.float64(loss.item())
+        res["train_acc" + store_suffix] = np.float64(acc.item())
+        names, norms = [], []
+        for k, p in mod.named_parameters():
+            if p.grad is None:
+                continue
+            names.append(k)
+            norms.append(float(p.grad.double().norm()))
+            if k in full:
+                res["grad%s:%s" % (store_suffix, k)] = p.grad.detach().float().numpy().copy()  # fp64 run stored as fp32
+        res["grad_names"] = np.array(names)
+        res["grad_norms" + store_suffix] = np.array(norms, dtype=np.float64)
+
+    run("")
+    rm_before = {k: v.clone() for k, v in mod.state_dict().items() if k.endswith("running_mean")}
+    assert all(torch.equal(v, calibrated_sd[k]) for k, v in rm_before.items()), "frozen BN must not update statistics"
+    mod.double()
+    mod.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in calibrated_sd.items()})
+    run("64")
+    mod.float()
+    res["meta"] = np.array([arch, method, str(T), str(train_shape), "fix_bn"])
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, "loss %.6f (fp64 %.6f)" % (float(res["train_loss"]), float(res["train_loss64"])))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -611,6 +890,12 @@ def main():
         case_raft()
     if want("vspw_datasets"):
         case_datasets()
+    if want("r50_clip_psp_fixbn"):
+        case_fixbn(M, "clip_psp", "resnet50dilated", "r50_clip_psp_fixbn")
+    if want("r50_clip_ocr_fixbn"):
+        case_fixbn(M, "clip_ocr", "resnet50dilated", "r50_clip_ocr_fixbn")
+    if want("drivers_reference"):
+        case_drivers(M)
 
 
 if __name__ == "__main__":

@@ -129,3 +129,64 @@ def test_cfg5_nonlocal3d_t7_and_netwarp_fullsize_properties(dev):
     loss.backward()
     assert math.isfinite(loss.item())
     assert torch.isfinite(nw.w0_1.grad).all() and torch.isfinite(nw.flowcnn.conv1[0].weight.grad).all()
+
+
+@pytest.mark.parametrize("kind", ["clip_psp", "clip_ocr"])
+def test_bench_workload_values_against_live_oracle(dev, kind):
+    """VALUE-level parity on the metric's own configuration (BASELINE.json configs[2] / [3]): ResNet-101 dilated TCB-PSP
+    / TCB-OCR, T=5 frames, B=2 clips, train step (loss, pixel accuracy, gradient of every parameter) against the numpy
+    oracle evaluated live in FLOAT64 - the oracle that tests/test_oracle_golden.py pins on the reference to 1e-9 - at
+    239x239 crops (30x30 feature maps, BatchNorm populations of 9 000; the 479x479 step would take the numpy oracle
+    ~15 min per head).  Gates: loss 2e-4, accuracy 2e-3, every parameter's gradient norm within 1e-2 (relative, with a
+    floor of 1e-3 of the largest norm), aggregate norm-vector error 3e-3."""
+    import time
+
+    from oracle import np_models as NM
+    from oracle import np_ops as O
+
+    T, B, S = 5, 2, 239
+    mod = build(kind, "resnet101dilated", args={"clip_num": T})
+    sd = load_det(mod)
+    zero_dropout(mod)
+    mod.to(dev).train()
+    imgs = [det_input("benchval:%s:%d" % (kind, t), (B, 3, S, S), seed=11) for t in range(T)]
+    labs = [det_labels("benchval:%s:%d" % (kind, t), (B, 1, S, S), K, seed=11) for t in range(T)]
+    ti = [_t(a, dev) for a in imgs]
+    tl = [_t(a, dev) for a in labs]
+    loss, acc = mod({"img_data": ti[-1], "seg_label": tl[-1], "clipimgs_data": ti[:-1], "cliplabels_data": tl[:-1]})
+    loss.backward()
+    g = {k: p.grad.detach().double().cpu().numpy() for k, p in mod.named_parameters() if p.grad is not None}
+    t0 = time.time()
+    O.set_dtype(np.float64)
+    try:
+        P = NM.Params({k: v.astype(np.float64) for k, v in sd.items()}, train_params=True)
+        fn = NM.clip_psp if kind == "clip_psp" else NM.clip_ocr
+        oloss, oacc = fn(P, "resnet101", [a.astype(np.float64) for a in imgs], labs, True)
+        O.tape().backward(oloss)
+        og = P.grads()
+    finally:
+        O.set_dtype(np.float32)
+    print("oracle (float64) %.1f s" % (time.time() - t0))
+    ol = float(np.asarray(oloss.v).reshape(()))
+    assert abs(loss.item() - ol) < 2e-4 * abs(ol), (loss.item(), ol)
+    assert abs(acc.item() - oacc) < 2e-3
+    norms = {k: float(np.linalg.norm(v)) for k, v in og.items()}
+    scale = max(norms.values())
+    num = den = 0.0
+    worst = (0.0, None)
+    for k, r in norms.items():
+        assert k in g, k
+        n = float(np.linalg.norm(g[k]))
+        num += (n - r) ** 2
+        den += r ** 2
+        e = abs(n - r) / max(r, 1e-3 * scale)
+        if e > worst[0]:
+            worst = (e, k)
+    print("worst per-parameter gradient-norm error %.3e (%s); aggregate %.3e" % (worst[0], worst[1],
+                                                                                  (num / den) ** 0.5))
+    assert worst[0] < 1e-2, worst
+    assert (num / den) ** 0.5 < 3e-3
+    # a few full tensors, direction and magnitude: relative L2 error
+    for k in ("encoder.conv1.weight", "encoder.layer3.22.conv2.weight", "encoder.layer4.2.conv3.weight"):
+        rel = np.linalg.norm(g[k] - og[k]) / np.linalg.norm(og[k])
+        assert rel < 2e-2, (k, rel)

@@ -1,8 +1,8 @@
 """End-to-end parity of the HIP-backed modules (through the C ABI) against
   (1) the golden vectors produced by the reference itself (tests/golden/*.npz), and
   (2) the numpy oracle run live on the same seeded inputs.
-Tolerances (north_star): eval logits within 1e-3 (or 4x the reference's own measured fp32 rounding error where that is
-larger — helpers.logit_tol), arg-max identical wherever the reference's top-2 logit gap exceeds 2*tol; training loss
+Tolerances (north_star): eval logits within 1e-3 (where the reference's own fp32 result is further than that from its
+float64 re-run: within 1.5x that measured error of the float64 logits — helpers.logit_tol / logit_error), arg-max identical wherever the reference's top-2 logit gap exceeds 2*tol; training loss
 within 2e-4 relative, per-parameter gradient norms within 8e-2 relative and 4e-2 in aggregate (fp32 gradients through ~50 train-mode BN
 layers on 9x9 maps are rounding-noisy: the oracle itself agrees with the reference only to that level in fp32 while
 agreeing to 1e-6 in float64, see tests/test_oracle_golden.py; on the GPU the fp32 MFMA k-sequential accumulation
@@ -13,8 +13,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import (K, build, check_argmax, check_grad_norms, clip_inputs, golden, load_det, logit_tol, seg_inputs,
-                     zero_dropout)
+from helpers import (K, build, check_argmax, check_grad_norms, clip_inputs, golden, load_det, logit_error, logit_tol,
+                     seg_inputs, zero_dropout)
 from oracle.det_init import det_input, det_labels
 
 pytestmark = pytest.mark.gpu
@@ -36,7 +36,7 @@ def _check_eval(fx, probs, store):
     tol = logit_tol(fx)
     probs = probs.detach().float().cpu().numpy()
     if "eval_logits" in fx.files:
-        err = np.abs(store["logits"] - fx["eval_logits"]).max()
+        err = logit_error(fx, store["logits"])
         assert err < tol, "logits err %.3e (tol %.1e)" % (err, tol)
     assert np.abs(probs[:, :, ::4, ::4] - fx["eval_probs_sub"]).max() < tol
     flips, near = check_argmax(probs.argmax(1), fx, tol)
@@ -374,3 +374,56 @@ def test_bench_shape_properties(dev):
         assert torch.isfinite(g1[k]).all(), k
         n1, n2 = g1[k].norm().item(), g2[k].norm().item()
         assert abs(n2 - 2 * n1) <= 1e-3 * max(n2, 1e-12), k
+
+
+@pytest.mark.parametrize("kind", ["clip_psp", "clip_ocr"])
+def test_frozen_bn_training_step_elementwise(dev, kind):
+    """cfg.TRAIN.fix_bn: loss + gradients with the module in eval mode (running statistics, no dropout), gated
+    ELEMENT-WISE on 113 stored gradient tensors (stem / layer1 / layer2 convolutions, every BatchNorm weight and bias)
+    against the reference's FLOAT64 run.
+
+    Measured (tools/diag/fixbn.py): even without batch statistics these random-weight gradients are ill-conditioned -
+    the reference's OWN fp32 gradients differ from its float64 ones by up to 4 % of a tensor's largest entry (0.7 % on
+    a parameter's norm; 65x65 crops, 9x9 maps, ReLU / max-pool decisions amplify fp32 rounding ~1e5-fold).  A flat 1e-3
+    gate is therefore not attainable by ANY fp32 implementation, the reference included; the HIP path is held to the
+    reference's own measured fp32 error instead: per tensor  |hip - ref64| <= max(1e-3, 6 x |ref32 - ref64|)  (largest
+    observed ratio 4.2), median ratio <= 2 (observed 1.3-1.4), per-parameter norm error RMS <= 2 x the reference's own
+    (observed 1.1-1.4 x) and <= 2e-2 anywhere; loss within 1e-5."""
+    tag = "r50_%s_fixbn" % kind
+    fx = golden(tag)
+    mod = build(kind, "resnet50dilated")
+    load_det(mod, fx=fx)
+    mod.to(dev)
+    inp = clip_inputs(tag)
+    mod.eval()  # train_clip2.py: segmentation_module.train(not cfg.TRAIN.fix_bn)
+    imgs = [_t(a, dev) for a in inp["train_imgs"]]
+    labs = [_t(a, dev) for a in inp["train_labs"]]
+    rm0 = mod.encoder.layer3[2].bn2.running_mean.clone()
+    loss, acc = mod({"img_data": imgs[-1], "seg_label": labs[-1], "clipimgs_data": imgs[:-1],
+                     "cliplabels_data": labs[:-1]})
+    loss.backward()
+    assert torch.equal(rm0, mod.encoder.layer3[2].bn2.running_mean), "frozen BN must not update its statistics"
+    ref_loss = float(fx["train_loss64"])
+    assert abs(loss.item() - ref_loss) < 1e-5 * abs(ref_loss), (loss.item(), ref_loss)
+    assert abs(acc.item() - float(fx["train_acc"])) < 2e-3
+    g = {k: v.astype(np.float64) for k, v in _grads(mod).items()}
+    names = [str(n) for n in fx["grad_names"]]
+    e_hip, e_ref = [], []
+    for n, r64, r32 in zip(names, fx["grad_norms64"], fx["grad_norms"]):
+        e_hip.append(abs(float(np.linalg.norm(g[n])) - r64) / r64)
+        e_ref.append(abs(r32 - r64) / r64)
+    e_hip, e_ref = np.array(e_hip), np.array(e_ref)
+    rms_hip, rms_ref = float(np.sqrt((e_hip ** 2).mean())), float(np.sqrt((e_ref ** 2).mean()))
+    assert rms_hip <= 2.0 * rms_ref, (rms_hip, rms_ref)
+    assert e_hip.max() < 2e-2, (e_hip.max(), names[int(e_hip.argmax())])
+    ratios = []
+    for key in fx.files:
+        if key.startswith("grad64:"):
+            ref = fx[key].astype(np.float64)
+            top = np.abs(ref).max()
+            eh = np.abs(g[key[7:]] - ref).max() / top
+            er = np.abs(fx["grad:" + key[7:]].astype(np.float64) - ref).max() / top
+            assert eh <= max(1e-3, 6.0 * er), (key, eh, er)
+            ratios.append(eh / max(er, 1e-12))
+    assert len(ratios) > 100
+    assert float(np.median(ratios)) <= 2.0, np.median(ratios)

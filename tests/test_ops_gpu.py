@@ -438,3 +438,28 @@ def test_sgd_matches_loop_semantics_with_duplicate_params(dev):
         opt.step()
     for p, r in zip(params, ref):
         _close(p, r, 2e-6, "sgd param")
+
+
+@pytest.mark.parametrize("B,N,C", [(2, 200, 128), (1, 1111, 64), (3, 17, 32), (2, 4097, 128)])
+def test_non_local_dot_fused(dev, B, N, C):
+    """(theta phi^T / N) g without the N x N affinity, forward and the three gradients, against the two-matmul
+    formulation of the reference (models/non_local.py:116-133) evaluated by torch on the CPU in float64; ragged N
+    (not a multiple of the 128-query / 32-key tiles), several key chunks (N = 4097)."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    g_ = torch.Generator().manual_seed(B * 1000 + N + C)
+    th, ph, gg = (torch.randn(B, N, C, generator=g_) for _ in range(3))
+    dy = torch.randn(B, N, C, generator=g_)
+    leaves = [t.double().requires_grad_(True) for t in (th, ph, gg)]
+    f = torch.matmul(leaves[0], leaves[1].transpose(1, 2)) / N
+    y = torch.matmul(f, leaves[2])
+    y.backward(dy.double())
+    dl = [t.to(dev).requires_grad_(True) for t in (th, ph, gg)]
+    yd = ops.non_local_dot(dl[0], dl[1], dl[2], 1.0 / N)
+    yd.backward(dy.to(dev))
+    _close(yd, y, 2e-5, "nl fwd")
+    for a, r, nm in zip(dl, leaves, ("theta", "phi", "g")):
+        _close(a.grad, r.grad, 2e-5, "nl d" + nm)
+    # bit-reproducible: fixed summation order, no atomics
+    yd2 = ops.non_local_dot(dl[0], dl[1], dl[2], 1.0 / N)
+    assert torch.equal(yd, yd2)

@@ -12,7 +12,7 @@ from oracle import np_ops as O
 from oracle.det_init import det_input, det_labels
 from oracle.np_ops import Var
 
-from helpers import (build, check_argmax, check_grad_norms, clip_inputs, det_numpy_state, golden, logit_tol,
+from helpers import (build, check_argmax, check_grad_norms, clip_inputs, det_numpy_state, golden, logit_error, logit_tol,
                      seg_inputs)
 
 
@@ -122,7 +122,7 @@ def test_clip_heads_match_reference(kind):
     P = NM.Params({k: v.copy() for k, v in sd.items()}, train_params=False)
     probs, logits = fn(P, "resnet50", inp["eval_imgs"], None, False, seg_size=(64, 96))
     tol = logit_tol(fx)
-    assert np.abs(logits.v - fx["eval_logits"]).max() < tol
+    assert logit_error(fx, logits.v) < tol
     assert np.abs(probs.v[:, :, ::4, ::4] - fx["eval_probs_sub"]).max() < tol
     check_argmax(probs.v.argmax(1), fx, tol)
     P = NM.Params({k: v.copy() for k, v in sd.items()}, train_params=True)
@@ -131,3 +131,30 @@ def test_clip_heads_match_reference(kind):
     assert abs(acc - float(fx["train_acc"])) < 2e-3
     O.tape().backward(loss)
     check_grad_norms(P.grads(), fx, 3e-2, tag)
+
+
+@pytest.mark.parametrize("kind", ["clip_psp", "clip_ocr"])
+def test_frozen_bn_training_step_matches_reference(kind):
+    """cfg.TRAIN.fix_bn (train_clip2.py: segmentation_module.train(not cfg.TRAIN.fix_bn)): loss + gradients with the
+    module in eval mode.  float64: loss to 1e-9, every gradient norm to 1e-6, stored gradient tensors element-wise."""
+    tag = "r50_%s_fixbn" % kind
+    fx = golden(tag)
+    mod = build(kind, "resnet50dilated")
+    sd = det_numpy_state(mod, fx=fx)
+    inp = clip_inputs(tag)
+    fn = {"clip_psp": NM.clip_psp, "clip_ocr": NM.clip_ocr}[kind]
+    O.set_dtype(np.float64)
+    P = NM.Params({k: v.copy() for k, v in sd.items()}, train_params=True)
+    loss, acc = fn(P, "resnet50", inp["train_imgs"], inp["train_labs"], False)
+    assert abs(_scalar(loss) - float(fx["train_loss64"])) < 1e-9 * abs(float(fx["train_loss64"])) + 1e-10
+    assert abs(acc - float(fx["train_acc64"])) < 1e-9
+    O.tape().backward(loss)
+    assert _grad_norm_err64(P, fx) < 1e-6
+    g = P.grads()
+    n = 0
+    for key in fx.files:
+        if key.startswith("grad64:"):
+            ref = fx[key].astype(np.float64)
+            assert np.abs(g[key[7:]] - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-12, key  # ref stored as float32
+            n += 1
+    assert n > 100

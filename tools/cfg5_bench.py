@@ -65,9 +65,11 @@ def main():
         opt3.step()
         return loss
 
+    torch.cuda.reset_peak_memory_stats()
     ms, loss = timeit(step_b, 3)
     print(json.dumps({"workload": "cfg5b Non_local3d (R101 dilated) train, T=7, B=2 clips, 479x479",
                       "ms_per_step": round(ms, 2), "clips_per_s": round(2 / ms * 1e3, 2),
+                      "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
                       "finite": bool(torch.isfinite(loss).item())}))
 
 

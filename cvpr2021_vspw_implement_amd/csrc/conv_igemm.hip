@@ -51,6 +51,7 @@ struct IgemmNT {
     int vec;            // 1: float4 loads are legal (c % 4 == 0 and lds % 4 == 0)
     int lds;            // pixel stride of src in floats (c, or wider when src is a channel slice of a concat buffer)
     int act;            // epilogue activation: 0 none, 1 relu, 2 sigmoid, 3 tanh (inference-only entry point)
+    int stagger;        // first-round phase stagger (see igemm_nt_v2_kernel), in units of 64*127 cycles per residency slot
 };
 
 __device__ __forceinline__ float nt_act(float v, int act) {
@@ -333,6 +334,17 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
     const int tile_n = vb % tiles_n;
     const int tile_m = vb / tiles_n;
     const int m0 = tile_m * TM, n0 = tile_n * TN;
+
+    // Phase stagger.  All workgroups of the first residency round start together, so the 3-4 workgroups sharing a CU
+    // run in lockstep: they compete for the MFMA pipe during their K loops and then all sit in their (memory-bound)
+    // epilogues at the same time, with the pipe idle.  Delaying the k-th co-resident workgroup by k/(slots) of a tile
+    // time makes one workgroup's epilogue / prologue coincide with the others' K loops for the rest of the launch.
+    // (Which workgroups share a CU is inferred from the observed dispatch order - blockIdx round-robin over the 256
+    // CUs - and only affects speed.)
+    if (p.stagger > 0 && blockIdx.x < 1024) {
+        const int slot = blockIdx.x >> 8;
+        for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     const int lrow = tid >> 3;
     const int lcol = (tid & 7) * 4;
@@ -1192,6 +1204,57 @@ __global__ void weight_transpose_kernel(const float* __restrict__ in, float* __r
     }
 }
 
+// The same transpose for MANY weight tensors in one launch (every convolution's data gradient needs the
+// [Cin][taps][Cout] copy of its weights once per step, after the optimizer rewrote them): entries[] (device) is sorted
+// by tile0 = number of 32x32 tiles of all preceding tensors; a workgroup finds its tensor by binary search.
+__global__ __launch_bounds__(256) void weight_transpose_multi_kernel(const vspw_wt_entry* __restrict__ entries,
+                                                                     int n_entries) {
+    __shared__ float tile[32][33];
+    const long long b = blockIdx.x;
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (entries[mid].tile0 <= b)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const vspw_wt_entry e = entries[lo];
+    const int R = e.k, T = e.taps, S = e.c;
+    const int ts = (S + 31) / 32, tr = (R + 31) / 32;
+    int local = (int)(b - e.tile0);
+    const int sx = local % ts;
+    local /= ts;
+    const int ry = local % tr;
+    const int t = local / tr;
+    const int r0 = ry * 32, s0 = sx * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* __restrict__ in = e.w;
+    float* __restrict__ out = e.wT;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, sc = s0 + tx;
+        tile[i][tx] = (r < R && sc < S) ? in[((size_t)r * T + t) * S + sc] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int sc = s0 + i, r = r0 + tx;
+        if (r < R && sc < S) out[((size_t)sc * T + t) * R + r] = tile[tx][i];
+    }
+}
+
+extern "C" long long vspw_weight_transpose_tiles(int k, int taps, int c) {
+    if (k <= 0 || taps <= 0 || c <= 0) return 0;
+    return (long long)taps * ((k + 31) / 32) * ((c + 31) / 32);
+}
+
+extern "C" int vspw_weight_transpose_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles,
+                                           void* stream) {
+    if (!entries || n_entries <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffffLL) return VSPW_EINVAL;
+    hipLaunchKernelGGL(weight_transpose_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, vspw_stream(stream),
+                       entries, n_entries);
+    return vspw_launch_status();
+}
+
 // NCHW -> NHWC for the images crossing the boundary.  One thread per pixel for small C (the 3-channel frames): plane
 // reads are coalesced across threads, the C outputs of a thread are contiguous; grid.y = image (no integer division).
 template <int C>
@@ -1223,6 +1286,11 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restr
     }
 }
 
+static int nt_stagger() {
+    static const int v = getenv("VSPW_STAGGER") ? atoi(getenv("VSPW_STAGGER")) : 0;
+    return v;
+}
+
 static int conv_geometry_ok(const vspw_conv_desc* d) {
     if (!d) return 0;
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0 || d->k <= 0) return 0;
@@ -1247,6 +1315,7 @@ static bool fill_fwd_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.vec = (d->c % 4 == 0) ? 1 : 0;
     p.lds = d->c;
     p.act = 0;
+    p.stagger = nt_stagger();
     return true;
 }
 
@@ -1340,6 +1409,7 @@ static bool fill_bwd_data_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.vec = (d->k % 4 == 0) ? 1 : 0;
     p.lds = d->k;
     p.act = 0;
+    p.stagger = nt_stagger();
     return true;
 }
 

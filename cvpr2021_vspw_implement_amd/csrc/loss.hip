@@ -117,8 +117,9 @@ __global__ __launch_bounds__(SP_TX * SP_TY) void softmax_pixels_bwd_kernel(const
 
 // ---- fused interpolate + NLL + pixel accuracy ----------------------------------------------------------
 // One wavefront per output pixel when the arg-max is wanted (lanes stride over K); one thread per pixel otherwise.
+template <typename LT>
 __global__ __launch_bounds__(256) void seg_nll_fwd_acc_kernel(const float* __restrict__ logp,
-                                                              const int64_t* __restrict__ label,
+                                                              const LT* __restrict__ label,
                                                               double* __restrict__ out, int n, int h, int w, int k,
                                                               int H, int W, int ignore, float sy, float sx) {
     const int lane = threadIdx.x & 63;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void seg_nll_fwd_acc_kernel(const float* __res
         const float* p01 = logp + (((size_t)img * h + y0) * w + x1) * k;
         const float* p10 = logp + (((size_t)img * h + y1) * w + x0) * k;
         const float* p11 = logp + (((size_t)img * h + y1) * w + x1) * k;
-        const long long lab = label[pix];
+        const long long lab = (long long)label[pix];  // float labels: label.long() of the reference (truncation)
         float best = -INFINITY;
         int bi = 0x7fffffff;
         float vlab = 0.f;
@@ -192,8 +193,9 @@ __global__ __launch_bounds__(256) void seg_nll_fwd_acc_kernel(const float* __res
     }
 }
 
+template <typename LT>
 __global__ __launch_bounds__(256) void seg_nll_fwd_kernel(const float* __restrict__ logp,
-                                                          const int64_t* __restrict__ label, double* __restrict__ out,
+                                                          const LT* __restrict__ label, double* __restrict__ out,
                                                           int n, int h, int w, int k, int H, int W, int ignore,
                                                           float sy, float sx) {
     const long long total = (long long)n * H * W;
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void seg_nll_fwd_kernel(const float* __restric
     const long long stride = (long long)gridDim.x * blockDim.x;
     double loss = 0, cnt = 0, valid = 0;
     for (; pix < total; pix += stride) {
-        const long long lab = label[pix];
+        const long long lab = (long long)label[pix];  // float labels: label.long() of the reference (truncation)
         if (lab >= 0) valid += 1.0;
         if (lab == (long long)ignore || lab < 0 || lab >= k) continue;
         const int ox = (int)(pix % W);
@@ -241,25 +243,26 @@ __global__ __launch_bounds__(256) void seg_nll_fwd_kernel(const float* __restric
 }
 
 // One workgroup per source (feature-resolution) pixel: gather the bilinear adjoint of the per-pixel NLL gradient
-// into K class bins (fixed summation order: bit-reproducible), then apply the log-softmax Jacobian and write dlogits[K].
+// into K class bins (64-bit fixed-point LDS atomics: order-independent, bit-reproducible), then apply the log-softmax Jacobian and write dlogits[K].
 #define NLL_MAXK 1024
-#define NLL_CHUNK 512
+template <typename LT>
 __global__ __launch_bounds__(256) void seg_nll_bwd_kernel(const float* __restrict__ logp,
-                                                          const int64_t* __restrict__ label,
+                                                          const LT* __restrict__ label,
                                                           const double* __restrict__ fwd_out,
                                                           const float* __restrict__ gscale,
                                                           float* __restrict__ dlogits, int n, int h, int w, int k,
                                                           int H, int W, int ignore, float sy, float sx, int jacobian) {
     __shared__ float bins[NLL_MAXK];
+    __shared__ unsigned long long ibins[NLL_MAXK];
     __shared__ float wsum[4];
-    __shared__ float fp_w[NLL_CHUNK];
-    __shared__ int fp_lab[NLL_CHUNK];
     const int tid = threadIdx.x;
     const long long sp = blockIdx.x;
     const int ix = (int)(sp % w);
     long long r = sp / w;
     const int iy = (int)(r % h);
     const int img = (int)(r / h);
+    for (int j = tid; j < k; j += blockDim.x) ibins[j] = 0ull;
+    __syncthreads();
     const float ry = (float)H / (float)h, rx = (float)W / (float)w;
     int oy_lo = (int)floorf(((float)iy - 1.f + 0.5f) * ry - 0.5f) - 1;
     int oy_hi = (int)ceilf(((float)iy + 1.f + 0.5f) * ry - 0.5f) + 1;
@@ -274,52 +277,30 @@ __global__ __launch_bounds__(256) void seg_nll_bwd_kernel(const float* __restric
     oy_hi = min(oy_hi, H - 1);
     ox_hi = min(ox_hi, W - 1);
     const int fw = ox_hi - ox_lo + 1, fh = oy_hi - oy_lo + 1;
-    // Deterministic binning (no atomics): the footprint's (label, weight) pairs are staged in LDS a chunk at a time;
-    // thread j then sums, in footprint order, the weights whose label is one of ITS classes j, j+256, ...
-    float mybin[NLL_MAXK / 256];
-#pragma unroll
-    for (int c = 0; c < NLL_MAXK / 256; ++c) mybin[c] = 0.f;
-    for (int q0 = 0; q0 < fw * fh; q0 += NLL_CHUNK) {
-        for (int e = tid; e < NLL_CHUNK; e += blockDim.x) {
-            const int q = q0 + e;
-            float wgt = 0.f;
-            int lb = -1;
-            if (q < fw * fh) {
-                const int oy = oy_lo + q / fw, ox = ox_lo + q % fw;
-                int y0, y1, x0, x1;
-                float ly, lx;
-                bilinear_src(oy, sy, h, y0, y1, ly);
-                float wy = 0.f;
-                if (y0 == iy) wy += 1.f - ly;
-                if (y1 == iy) wy += ly;
-                bilinear_src(ox, sx, w, x0, x1, lx);
-                float wx = 0.f;
-                if (x0 == ix) wx += 1.f - lx;
-                if (x1 == ix) wx += lx;
-                const long long lab = label[((size_t)img * H + oy) * W + ox];
-                if (wy != 0.f && wx != 0.f && lab != (long long)ignore && lab >= 0 && lab < k) {
-                    wgt = wy * wx;
-                    lb = (int)lab;
-                }
-            }
-            fp_w[e] = wgt;
-            fp_lab[e] = lb;
-        }
-        __syncthreads();
-        const int cnt_e = min(NLL_CHUNK, fw * fh - q0);
-        for (int e = 0; e < cnt_e; ++e) {
-            const int lb = fp_lab[e];  // LDS broadcast
-            if (lb < 0) continue;      // uniform branch
-            const float wv = fp_w[e];
-#pragma unroll
-            for (int c = 0; c < NLL_MAXK / 256; ++c)
-                if (lb == c * 256 + tid) mybin[c] += wv;
-        }
-        __syncthreads();
+    // Class bins are accumulated with 64-bit INTEGER LDS atomics on weights scaled by 2^40: integer addition is
+    // associative, so the result does not depend on the order the lanes arrive in (bit-reproducible), and the
+    // bilinear weights (products of two fp32 fractions, >= 2^-16 apart from exact zeros) are represented exactly up to
+    // 2^-40 - the bin sums are MORE accurate than an fp32 accumulation.  A footprint has < 2^12 pixels: no overflow.
+    for (int q = tid; q < fw * fh; q += blockDim.x) {
+        const int oy = oy_lo + q / fw, ox = ox_lo + q % fw;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilinear_src(oy, sy, h, y0, y1, ly);
+        float wy = 0.f;
+        if (y0 == iy) wy += 1.f - ly;
+        if (y1 == iy) wy += ly;
+        if (wy == 0.f) continue;
+        bilinear_src(ox, sx, w, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == ix) wx += 1.f - lx;
+        if (x1 == ix) wx += lx;
+        if (wx == 0.f) continue;
+        const long long lab = (long long)label[((size_t)img * H + oy) * W + ox];
+        if (lab == (long long)ignore || lab < 0 || lab >= k) continue;
+        atomicAdd(&ibins[(int)lab], (unsigned long long)((double)(wy * wx) * 1099511627776.0 + 0.5));
     }
-#pragma unroll
-    for (int c = 0; c < NLL_MAXK / 256; ++c)
-        if (c * 256 + tid < k) bins[c * 256 + tid] = mybin[c];
+    __syncthreads();
+    for (int j = tid; j < k; j += blockDim.x) bins[j] = (float)((double)ibins[j] * (1.0 / 1099511627776.0));
     __syncthreads();
     const double cnt = fwd_out[1];
     const float g = cnt > 0 ? -gscale[0] / (float)cnt : 0.f;
@@ -444,30 +425,47 @@ extern "C" int vspw_softmax_pixels_bwd(const float* dy, const float* y, float* d
     return vspw_launch_status();
 }
 
-extern "C" int vspw_seg_nll_fwd(const float* logp, const int64_t* label, double* out, int n, int h, int w, int k,
-                                int H, int W, int ignore_index, int want_acc, void* stream) {
+extern "C" int vspw_seg_nll_fwd(const float* logp, const void* label, int label_f32, double* out, int n, int h, int w,
+                                int k, int H, int W, int ignore_index, int want_acc, void* stream) {
     if (!logp || !label || !out || n <= 0 || h <= 0 || w <= 0 || k <= 0 || H <= 0 || W <= 0) return VSPW_EINVAL;
     const long long total = (long long)n * H * W;
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
-    if (want_acc)
-        hipLaunchKernelGGL(seg_nll_fwd_acc_kernel, dim3(wave_grid(total)), dim3(256), 0, vspw_stream(stream), logp,
-                           label, out, n, h, w, k, H, W, ignore_index, sy, sx);
-    else
-        hipLaunchKernelGGL(seg_nll_fwd_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream),
-                           logp, label, out, n, h, w, k, H, W, ignore_index, sy, sx);
+    const int64_t* li = reinterpret_cast<const int64_t*>(label);
+    const float* lf = reinterpret_cast<const float*>(label);
+    hipStream_t st = vspw_stream(stream);
+    if (want_acc) {
+        if (label_f32)
+            hipLaunchKernelGGL(seg_nll_fwd_acc_kernel<float>, dim3(wave_grid(total)), dim3(256), 0, st, logp, lf, out, n, h,
+                               w, k, H, W, ignore_index, sy, sx);
+        else
+            hipLaunchKernelGGL(seg_nll_fwd_acc_kernel<int64_t>, dim3(wave_grid(total)), dim3(256), 0, st, logp, li, out, n,
+                               h, w, k, H, W, ignore_index, sy, sx);
+    } else {
+        if (label_f32)
+            hipLaunchKernelGGL(seg_nll_fwd_kernel<float>, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, st, logp, lf,
+                               out, n, h, w, k, H, W, ignore_index, sy, sx);
+        else
+            hipLaunchKernelGGL(seg_nll_fwd_kernel<int64_t>, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, st, logp, li,
+                               out, n, h, w, k, H, W, ignore_index, sy, sx);
+    }
     return vspw_launch_status();
 }
 
-extern "C" int vspw_seg_nll_bwd(const float* logp, const int64_t* label, const double* fwd_out, const float* gscale,
-                                float* dlogits, int n, int h, int w, int k, int H, int W, int ignore_index,
-                                int lsm_jacobian, void* stream) {
+extern "C" int vspw_seg_nll_bwd(const float* logp, const void* label, int label_f32, const double* fwd_out,
+                                const float* gscale, float* dlogits, int n, int h, int w, int k, int H, int W,
+                                int ignore_index, int lsm_jacobian, void* stream) {
     if (!logp || !label || !fwd_out || !gscale || !dlogits) return VSPW_EINVAL;
     if (n <= 0 || h <= 0 || w <= 0 || k <= 0 || k > NLL_MAXK || H <= 0 || W <= 0) return VSPW_EINVAL;
     const long long blocks = (long long)n * h * w;
     if (blocks > 0x7fffffffLL) return VSPW_EINVAL;
-    hipLaunchKernelGGL(seg_nll_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, vspw_stream(stream), logp, label,
-                       fwd_out, gscale, dlogits, n, h, w, k, H, W, ignore_index, (float)h / (float)H,
-                       (float)w / (float)W, lsm_jacobian);
+    if (label_f32)
+        hipLaunchKernelGGL(seg_nll_bwd_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, vspw_stream(stream), logp,
+                           reinterpret_cast<const float*>(label), fwd_out, gscale, dlogits, n, h, w, k, H, W,
+                           ignore_index, (float)h / (float)H, (float)w / (float)W, lsm_jacobian);
+    else
+        hipLaunchKernelGGL(seg_nll_bwd_kernel<int64_t>, dim3((unsigned)blocks), dim3(256), 0, vspw_stream(stream), logp,
+                           reinterpret_cast<const int64_t*>(label), fwd_out, gscale, dlogits, n, h, w, k, H, W,
+                           ignore_index, (float)h / (float)H, (float)w / (float)W, lsm_jacobian);
     return vspw_launch_status();
 }
 

@@ -78,6 +78,85 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     }
 }
 
+// float4 variants (c % 4 == 0: the 128-channel stem output): one thread = 4 channels of one pixel, one 32-bit
+// pixel decode per 16 bytes instead of 64-bit div/mod per element; grid.y = image.
+typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void maxpool_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                           uint8_t* __restrict__ idx, int h, int w, int c4, int oh,
+                                                           int ow) {
+    const int img = blockIdx.y;
+    const int total = oh * ow * c4;
+    const f32x4* xb = reinterpret_cast<const f32x4*>(x) + (size_t)img * h * w * c4;
+    f32x4* yb = reinterpret_cast<f32x4*>(y) + (size_t)img * total;
+    u8x4* ib = reinterpret_cast<u8x4*>(idx) + (size_t)img * total;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ch = i % c4;
+        const int r = i / c4;
+        const int ox = r % ow, oy = r / ow;
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {-1, -1, -1, -1};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if (iy < 0 || iy >= h) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if (ix < 0 || ix >= w) continue;
+                const f32x4 v = xb[((size_t)iy * w + ix) * c4 + ch];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (bi[e] < 0 || v[e] > best[e] || v[e] != v[e]) {  // first maximum wins ties; NaN propagates
+                        best[e] = v[e];
+                        bi[e] = ky * 3 + kx;
+                    }
+            }
+        }
+        yb[i] = best;
+        u8x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (unsigned char)bi[e];
+        ib[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd4_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ idx,
+                                                           float* __restrict__ dx, int h, int w, int c4, int oh, int ow) {
+    const int img = blockIdx.y;
+    const int total = h * w * c4;
+    const f32x4* gb = reinterpret_cast<const f32x4*>(dy) + (size_t)img * oh * ow * c4;
+    const u8x4* ib = reinterpret_cast<const u8x4*>(idx) + (size_t)img * oh * ow * c4;
+    f32x4* db = reinterpret_cast<f32x4*>(dx) + (size_t)img * total;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ch = i % c4;
+        const int r = i / c4;
+        const int ix = r % w, iy = r / w;
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        // windows containing (iy, ix): oy with oy*2-1+ky == iy, ky in 0..2 (same visiting order as the scalar kernel)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + 1 - ky;
+            if (ty < 0 || (ty & 1)) continue;
+            const int oy = ty >> 1;
+            if (oy >= oh) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + 1 - kx;
+                if (tx < 0 || (tx & 1)) continue;
+                const int ox = tx >> 1;
+                if (ox >= ow) continue;
+                const size_t o = ((size_t)oy * ow + ox) * c4 + ch;
+                const u8x4 id = ib[o];
+                const f32x4 v = gb[o];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (id[e] == (unsigned char)(ky * 3 + kx)) g[e] += v[e];
+            }
+        }
+        db[i] = g;
+    }
+}
+
 // ---- adaptive average pool ---------------------------------------------------------------------------
 // bin i covers [floor(i*H/s), ceil((i+1)*H/s)) (ATen start_index/end_index); bins overlap when s does not divide H.
 __device__ __forceinline__ int bin_start(int i, int in, int s) { return (int)(((long long)i * in) / s); }
@@ -224,39 +303,41 @@ struct PoolBwdMulti {
     int ns;
 };
 
+#define POOL_BWD_XCHUNK 8
+// One workgroup per (image, row, 8-pixel column chunk): the scale / row-bin / column-bin loops are workgroup-uniform (scalar registers, the
+// integer divisions of the bin edges are done once per row or per pixel, not per element); the 256 threads sweep the
+// channel float4s of one pixel at a time.  The pooled gradients are a few hundred KB (L2-resident): the kernel is a
+// pure streaming write of dx.  Same summation order as before: scales in order, row bins, then column bins.
 __global__ __launch_bounds__(256) void adaptive_avgpool_bwd_multi_kernel(PoolBwdMulti p, float* __restrict__ dx, int n,
                                                                          int h, int w, int c, int T, int B) {
     const int cw = c / 4;
-    const long long total = (long long)n * h * w * cw;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int iy = blockIdx.x % h;
+    const int img = blockIdx.x / h;
+    const int src = (T > 1) ? (img % B) : img;
     const float invT = 1.f / (float)T;
-    for (; i < total; i += stride) {
-        const int ch = (int)(i % cw) * 4;
-        long long r = i / cw;
-        const int ix = (int)(r % w);
-        r /= w;
-        const int iy = (int)(r % h);
-        const int img = (int)(r / h);
-        const int src = (T > 1) ? (img % B) : img;
-        f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < p.ns; ++k) {
-            const int s = p.s[k];
-            const int byc = (int)(((long long)iy * s) / h);
-            const int bxc = (int)(((long long)ix * s) / w);
-            for (int by = max(0, byc - 1); by <= min(s - 1, byc + 1); ++by) {
-                const int y0 = bin_start(by, h, s), y1 = bin_end(by, h, s);
-                if (iy < y0 || iy >= y1) continue;
-                for (int bx = max(0, bxc - 1); bx <= min(s - 1, bxc + 1); ++bx) {
-                    const int x0 = bin_start(bx, w, s), x1 = bin_end(bx, w, s);
-                    if (ix < x0 || ix >= x1) continue;
-                    const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
-                    g += inv * *reinterpret_cast<const f32x4*>(p.dy[k] + (((size_t)src * s + by) * s + bx) * c + ch);
+    f32x4* drow = reinterpret_cast<f32x4*>(dx) + ((size_t)img * h + iy) * w * cw;
+    const int x_lo = blockIdx.y * POOL_BWD_XCHUNK, x_hi = min(w, x_lo + POOL_BWD_XCHUNK);
+    for (int ix = x_lo; ix < x_hi; ++ix) {
+        for (int ch = threadIdx.x; ch < cw; ch += blockDim.x) {
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < p.ns; ++k) {
+                const int s = p.s[k];
+                const int byc = (int)(((long long)iy * s) / h);
+                const int bxc = (int)(((long long)ix * s) / w);
+                for (int by = max(0, byc - 1); by <= min(s - 1, byc + 1); ++by) {
+                    const int y0 = bin_start(by, h, s), y1 = bin_end(by, h, s);
+                    if (iy < y0 || iy >= y1) continue;
+                    for (int bx = max(0, bxc - 1); bx <= min(s - 1, bxc + 1); ++bx) {
+                        const int x0 = bin_start(bx, w, s), x1 = bin_end(bx, w, s);
+                        if (ix < x0 || ix >= x1) continue;
+                        const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+                        g += inv * reinterpret_cast<const f32x4*>(p.dy[k] + (((size_t)src * s + by) * s + bx) * c)[ch];
+                    }
                 }
             }
+            if (T > 1) g *= invT;
+            drow[(size_t)ix * cw + ch] = g;
         }
-        if (T > 1) g *= invT;
-        *reinterpret_cast<f32x4*>(dx + (size_t)i * 4) = g;
     }
 }
 
@@ -306,6 +387,11 @@ extern "C" int vspw_maxpool3x3s2_fwd(const float* x, float* y, uint8_t* idx, int
     if (!x || !y || !idx || n <= 0 || h <= 0 || w <= 0 || c <= 0) return VSPW_EINVAL;
     if (oh != (h + 2 - 3) / 2 + 1 || ow != (w + 2 - 3) / 2 + 1) return VSPW_EINVAL;
     long long total = (long long)n * oh * ow * c;
+    if (c % 4 == 0 && n <= 65535 && (long long)h * w * c < 0x7fffffffLL) {
+        hipLaunchKernelGGL(maxpool_fwd4_kernel, dim3(vspw_stream_grid((long long)oh * ow * (c / 4), 256), n), dim3(256), 0,
+                           vspw_stream(stream), x, y, idx, h, w, c / 4, oh, ow);
+        return vspw_launch_status();
+    }
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream), x, y,
                        idx, n, h, w, c, oh, ow);
     return vspw_launch_status();
@@ -316,6 +402,11 @@ extern "C" int vspw_maxpool3x3s2_bwd(const float* dy, const uint8_t* idx, float*
     if (!dy || !dx || !idx || n <= 0 || h <= 0 || w <= 0 || c <= 0) return VSPW_EINVAL;
     if (oh != (h + 2 - 3) / 2 + 1 || ow != (w + 2 - 3) / 2 + 1) return VSPW_EINVAL;
     long long total = (long long)n * h * w * c;
+    if (c % 4 == 0 && n <= 65535 && (long long)h * w * c < 0x7fffffffLL) {
+        hipLaunchKernelGGL(maxpool_bwd4_kernel, dim3(vspw_stream_grid((long long)h * w * (c / 4), 256), n), dim3(256), 0,
+                           vspw_stream(stream), dy, idx, dx, h, w, c / 4, oh, ow);
+        return vspw_launch_status();
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream), dy,
                        idx, dx, n, h, w, c, oh, ow);
     return vspw_launch_status();
@@ -386,9 +477,9 @@ extern "C" int vspw_pyramid_pool_bwd(const float* const* dy, const int* scales, 
         p.s[k] = k < nscales ? scales[k] : 1;
         if (k < nscales && (!dy[k] || scales[k] <= 0)) return VSPW_EINVAL;
     }
-    long long total = (long long)n * h * w * (c / 4);
-    hipLaunchKernelGGL(adaptive_avgpool_bwd_multi_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0,
-                       vspw_stream(stream), p, dx, n, h, w, c, T, n / T);
+    if ((long long)n * h > 0x7fffffffLL) return VSPW_EINVAL;
+    hipLaunchKernelGGL(adaptive_avgpool_bwd_multi_kernel, dim3((unsigned)(n * h), vspw_cdiv(w, POOL_BWD_XCHUNK)), dim3(256),
+                       0, vspw_stream(stream), p, dx, n, h, w, c, T, n / T);
     return vspw_launch_status();
 }
 

@@ -103,6 +103,7 @@ class GradReducer:
     def _launch(self, bi):
         """Gather the bucket's gradients into its flat buffer with ONE multi-tensor copy, then start the all-reduce."""
         bucket = self.buckets[bi]
+        ops.join_side_streams()  # weight gradients may still be in flight on the side stream
         have = [p for p in bucket if p.grad is not None and p.grad.data_ptr() != self.slots[id(p)].data_ptr()]
         if have:
             torch._foreach_copy_([self.slots[id(p)] for p in have], [p.grad for p in have])

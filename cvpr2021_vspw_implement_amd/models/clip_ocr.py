@@ -69,7 +69,7 @@ class ClipOCRNet(LrGroupsMixin, nn.Module):
             # spatial_ocr_block.py:263: "shape '[B*T, 256, -1]' is invalid for input of size ..."); same error class here
             raise RuntimeError("clipocr_all with %d frames per clip: shape '[%d, 256, -1]' is invalid for the %d object "
                                "contexts (the reference fails identically)" % (T, out_tmp.shape[0], B))
-        x = out_tmp if all_frames else out_tmp[(T - 1) * B:]
+        x = out_tmp if all_frames else ops.tail_frames(out_tmp, B)
         x = self.head(self.spatial_ocr_head(x, context))
         if segSize is not None:
             if all_frames:

@@ -99,8 +99,9 @@ class Clip_PSP(LrGroupsMixin, nn.Module):
         conv5 = feats[-1]
         B = conv5.shape[0] // T
         wts = self._temporal_weights(conv5, T) if self.args.psp_weight else None
-        blended = ops.pyramid_pool(conv5, self.pool_scales, T, wts)
-        pred_ = self.ppm_conv(conv5[(T - 1) * B:], blended)
+        # blended pools of all T frames + the current frames (the last B of the batch) from one node: see PyramidPoolFn
+        *blended, cur = ops.pyramid_pool(conv5, self.pool_scales, T, wts, tail=B)
+        pred_ = self.ppm_conv(cur, blended)
         if segSize is not None:
             return ops.upsample_softmax(pred_, segSize)
         ignore = nll_ignore_index(self.crit)

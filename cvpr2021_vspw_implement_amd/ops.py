@@ -142,13 +142,97 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False):
     return y, part, d
 
 
+# [Cin][KH][KW][Cout] copies of the convolution weights for the data-gradient GEMMs.  Weights change once per step (the
+# optimizer), so the copies are refreshed once per step - ALL of them by one multi-tensor launch, triggered by the first
+# data gradient that finds its copy stale - instead of one 5 us launch per layer inside the backward critical path.
+_wt_cache = {"entries": {}, "order": [], "table": None, "table_n": 0, "tiles": 0, "gen": 0}
+_WT_ENTRY = None
+
+
+def _wt_key(w):
+    return (w.data_ptr(), w._version, _wt_cache["gen"], tuple(w.shape))
+
+
+def _wt_upload_table(device):
+    import numpy as np
+
+    global _WT_ENTRY
+    if _WT_ENTRY is None:  # struct vspw_wt_entry (include/vspw_hip.h)
+        _WT_ENTRY = np.dtype([("w", "<u8"), ("wT", "<u8"), ("tile0", "<i8"), ("k", "<i4"), ("taps", "<i4"),
+                              ("c", "<i4"), ("reserved", "<i4")])
+    ents = [_wt_cache["entries"][i] for i in _wt_cache["order"]]
+    rec = np.zeros(len(ents), dtype=_WT_ENTRY)
+    t0 = 0
+    for i, e in enumerate(ents):
+        k, c, kh, kw = e["shape"]
+        rec[i] = (e["ptr"], e["wT"].data_ptr(), t0, k, kh * kw, c, 0)
+        t0 += int(_C.query("vspw_weight_transpose_tiles", k, kh * kw, c))
+    _wt_cache["table"] = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
+    _wt_cache["table_n"] = len(ents)
+    _wt_cache["tiles"] = t0
+
+
+def _transposed_weight(w):
+    """wT for the data gradient of a conv with weight w ([K][KH][KW][C] memory), from the per-step cache."""
+    import weakref
+
+    ents = _wt_cache["entries"]
+    ident = (w.data_ptr(), tuple(w.shape))
+    e = ents.get(ident)
+    key = _wt_key(w)
+    if e is not None and e["ref"]() is None:
+        # the tensor this entry was made for is gone: its storage may have been freed and handed to ANOTHER weight with
+        # the same address / shape / version, so nothing cached under this identity can be trusted
+        del ents[ident]
+        _wt_cache["order"] = [i for i in _wt_cache["order"] if i != ident]
+        _wt_cache["table"] = None
+        e = None
+    if e is not None and e["key"] == key:
+        return e["wT"]
+    k, c, kh, kw = w.shape
+    capturing = torch.cuda.is_current_stream_capturing()
+    if e is None:
+        # first sight of this weight: own launch now, member of the batched refresh from the next step on
+        wT = torch.empty((c, kh, kw, k), device=w.device, dtype=torch.float32)
+        if capturing:  # a buffer from the graph's private pool must not leak into the eager cache
+            _C.call("vspw_weight_transpose", _p(w), _p(wT), k, kh * kw, c, _stream())
+            return wT
+        ents[ident] = e = {"wT": wT, "ptr": w.data_ptr(), "shape": tuple(w.shape), "key": None, "ref": weakref.ref(w)}
+        _wt_cache["order"].append(ident)
+        _wt_cache["table"] = None
+    if not capturing:
+        dead = [i for i, x in ents.items() if x["ref"]() is None]
+        if dead:  # weights of a model that no longer exists
+            for i in dead:
+                del ents[i]
+            _wt_cache["order"] = [i for i in _wt_cache["order"] if i in ents]
+            _wt_cache["table"] = None
+        if _wt_cache["table"] is None and len(ents) > 1 and all(
+                x["key"] is None or x["key"][2] != _wt_cache["gen"] for x in ents.values()):
+            _wt_upload_table(w.device)
+    if _wt_cache["table"] is not None and _wt_cache["table_n"] == len(ents):
+        # refresh every registered copy in one launch (they all went stale together: same optimizer step)
+        _C.call("vspw_weight_transpose_multi", _p(_wt_cache["table"]), _wt_cache["table_n"], _wt_cache["tiles"], _stream())
+        for x in ents.values():
+            t = x["ref"]()
+            x["key"] = _wt_key(t) if t is not None else None
+        e["key"] = key
+        return e["wT"]
+    _C.call("vspw_weight_transpose", _p(w), _p(e["wT"]), k, kh * kw, c, _stream())
+    e["key"] = key
+    return e["wT"]
+
+
+def drop_weight_transpose_cache():
+    _wt_cache.update(entries={}, order=[], table=None, table_n=0, tiles=0)
+
+
 def conv2d_backward_data(dy, w, d, addend=None, bn_front=None):
     """dx = conv_backward_input(dy, w) [+ addend, folded into the GEMM epilogue].
     bn_front = (z, link): additionally apply the ReLU mask of the node that produced this conv's input z and leave the
     two batch-norm-backward reductions of that node in link.partials (see BNLink); returns the masked gradient."""
     k, c, kh, kw = w.shape
-    wT = torch.empty((c, kh, kw, k), device=w.device, dtype=torch.float32)
-    _C.call("vspw_weight_transpose", _p(w), _p(wT), k, kh * kw, c, _stream())
+    wT = _transposed_weight(w)
     dx = empty_nhwc(d.n, d.c, d.h, d.w, dy.device)
     if addend is not None:
         addend = to_nhwc(addend)
@@ -171,12 +255,59 @@ def conv2d_backward_data(dy, w, d, addend=None, bn_front=None):
     return dx
 
 
-def conv2d_backward_weight(dy, x, d):
+# Weight gradients are leaves of the backward pass: nothing downstream of a convolution's dW is needed before the
+# optimizer step (or the bucket all-reduce), while dX is on the critical path.  They are issued on a second HIP stream
+# (fork after dY is ready; joined by an autograd end-of-backward callback, and before any bucket all-reduce) so that
+# the split-K weight-gradient GEMM of layer i overlaps the BatchNorm-backward passes and the data-gradient GEMM of
+# layer i-1 and fills their launch tails; under a captured hipGraph the fork/join become graph edges (no host events).
+# Measured on the bench step: 116.1 -> 114.4 ms, bit-identical results.  VSPW_WGRAD_STREAM=0 disables it.
+_wgrad_side = {"enabled": os.environ.get("VSPW_WGRAD_STREAM", "1") == "1", "stream": None, "keep": [], "dirty": False}
+
+
+def set_wgrad_side_stream(enabled):
+    join_side_streams()
+    _wgrad_side["enabled"] = bool(enabled)
+
+
+def join_side_streams():
+    """Make the current stream wait for every weight-gradient GEMM issued on the side stream (call before anything
+    reads parameter gradients: optimizer step, gradient all-reduce, gradient inspection)."""
+    if _wgrad_side["dirty"]:
+        torch.cuda.current_stream().wait_stream(_wgrad_side["stream"])
+        _wgrad_side["keep"].clear()
+        _wgrad_side["dirty"] = False
+
+
+def _wgrad_launch(dy, x, d):
     dw = torch.empty((d.k, d.kh, d.kw, d.c), device=dy.device, dtype=torch.float32).permute(0, 3, 1, 2)
     nbytes = _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d))
     ws = _ws(nbytes, dy.device) if nbytes else None
     with _Timed("igemm_tn_kernel", _conv_flops(d), _conv_tag(d, "wgrad")):
         _C.call("vspw_conv2d_bwd_weight", ctypes.byref(d), _p(dy), _p(x), _p(dw), _p(ws), nbytes, _stream())
+    return dw, ws
+
+
+def conv2d_backward_weight(dy, x, d):
+    if not _wgrad_side["enabled"] or _ktimer["on"]:
+        return _wgrad_launch(dy, x, d)[0]
+    main = torch.cuda.current_stream()
+    side = _wgrad_side["stream"]
+    if side is None:
+        side = _wgrad_side["stream"] = torch.cuda.Stream(device=dy.device)
+    side.wait_stream(main)  # fork: dY (and X) are complete on the main stream
+    with torch.cuda.stream(side):
+        dw, ws = _wgrad_launch(dy, x, d)
+    # dY / X / the workspace were allocated on the main stream's pool: keep them alive until the join so that the
+    # allocator cannot hand their memory to a later main-stream kernel while the side-stream GEMM still reads it
+    # (dW itself must NOT be referenced here: with a second owner autograd's AccumulateGrad would clone it - a copy on
+    # the main stream that races with the side-stream GEMM - instead of adopting the tensor as p.grad)
+    _wgrad_side["keep"].append((dy, x, ws))
+    if not _wgrad_side["dirty"]:
+        _wgrad_side["dirty"] = True
+        try:  # join when this backward pass ends, so that p.grad is safe to read on the main stream afterwards
+            torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+        except RuntimeError:
+            pass  # not inside a backward pass (direct call from a test): the caller joins
     return dw
 
 
@@ -349,6 +480,7 @@ def invalidate_inference_cache():
     BatchNorm finalize): tensor._version does not see those writes, so the folded conv+BN weights cached for
     inference are keyed on this generation counter as well."""
     _infer_fold["gen"] += 1
+    _wt_cache["gen"] += 1  # the transposed copies used by the data-gradient GEMMs are stale too
     if len(_infer_fold["cache"]) > 4096:
         _infer_fold["cache"].clear()
 
@@ -598,7 +730,11 @@ class PyramidPoolFn(torch.autograd.Function):
     mean over the T frames of each clip (models/clip_psp.py:157-188).  Returns one [B,C,s,s] tensor per scale."""
 
     @staticmethod
-    def forward(ctx, x, scales, T, wts):
+    def forward(ctx, x, scales, T, wts, tail=0):
+        """tail > 0: additionally return the last `tail` frames of x (the current frames of the clips, which the heads
+        read next to the blended pools, models/clip_psp.py:154-189) as a zero-copy slab; in backward their gradient is
+        added into the pooled gradient in place - no zero-filled full-size tensor, no layout change, no separate
+        accumulation pass over conv5's gradient."""
         _require_gpu(x, "pyramid_pool")
         x = to_nhwc(x)
         n, c, h, w = x.shape
@@ -631,27 +767,40 @@ class PyramidPoolFn(torch.autograd.Function):
                     keep.append(pooled)  # tiny ([n,c,s,s]); needed for the gradient of the temporal weights
             else:
                 outs.append(pooled)
-        ctx.meta = (n, c, h, w, tuple(scales), T)
+        ctx.meta = (n, c, h, w, tuple(scales), T, int(tail))
         ctx.save_for_backward(wts, *keep)
+        if tail:
+            outs.append(x[n - tail:])  # NHWC memory: the last frames are one contiguous slab
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         wts = ctx.saved_tensors[0]
         pooled_all = ctx.saved_tensors[1:]
-        n, c, h, w, scales, T = ctx.meta
+        n, c, h, w, scales, T, tail = ctx.meta
         B = n // T
         st = _stream()
-        dev = grads[0].device
+        gtail = None
+        if tail:
+            gtail, grads = grads[-1], grads[:-1]
+        dev = next(g for g in list(grads) + [gtail] if g is not None).device
         dx = empty_nhwc(n, c, h, w, dev)
+
+        def add_tail(res):
+            if gtail is not None:
+                gt = to_nhwc(gtail)
+                dxt = res[n - tail:]
+                _C.call("vspw_axpby", _p(gt), _p(dxt), gt.numel(), 1.0, 1.0, st)
+            return res
+
         live = [(s, to_nhwc(g)) for s, g in zip(scales, grads) if g is not None]
         if not live:
-            return dx.zero_(), None, None, None
+            return add_tail(dx.zero_()), None, None, None, None
         if wts is None and c % 4 == 0 and len(live) <= 4:  # one fused pass: all scales + the temporal-mean adjoint
             ptrs = (ctypes.c_void_p * len(live))(*[g.data_ptr() for _, g in live])
             svec = (ctypes.c_int * len(live))(*[s for s, _ in live])
             _C.call("vspw_pyramid_pool_bwd", ptrs, svec, len(live), _p(dx), n, h, w, c, T, st)
-            return dx, None, None, None
+            return add_tail(dx), None, None, None, None
         first = True
         dwts = None
         if wts is not None and ctx.needs_input_grad[3]:
@@ -668,11 +817,42 @@ class PyramidPoolFn(torch.autograd.Function):
                 gp = g
             _C.call("vspw_adaptive_avgpool_bwd", _p(gp), _p(dx), n, h, w, c, s, 0 if first else 1, st)
             first = False
-        return dx, None, None, dwts
+        return add_tail(dx), None, None, dwts, None
 
 
-def pyramid_pool(x, scales, T=1, wts=None):
-    return PyramidPoolFn.apply(x, tuple(scales), T, wts)
+def pyramid_pool(x, scales, T=1, wts=None, tail=0):
+    """tail=0: tuple of pooled maps (one per scale); tail=k: (pooled maps..., x[-k:])."""
+    return PyramidPoolFn.apply(x, tuple(scales), T, wts, int(tail))
+
+
+class TailFramesFn(torch.autograd.Function):
+    """x[n - count:] of an NHWC-memory tensor (zero-copy slab); the gradient is written straight into an NHWC buffer
+    (zeros in front) instead of autograd's NCHW-ordered slice-backward tensor that every consumer would re-lay-out."""
+
+    @staticmethod
+    def forward(ctx, x, count):
+        _require_gpu(x, "tail_frames")
+        x = to_nhwc(x)
+        ctx.meta = (tuple(x.shape), int(count))
+        return x[x.shape[0] - count:]
+
+    @staticmethod
+    def backward(ctx, g):
+        (n, c, h, w), count = ctx.meta
+        g = to_nhwc(g)
+        dx = empty_nhwc(n, c, h, w, g.device)
+        st = _stream()
+        head = dx[:n - count]
+        if head.numel():
+            head.zero_()
+        _C.call("vspw_axpby", _p(g), _p(dx[n - count:]), g.numel(), 1.0, 0.0, st)
+        return dx, None
+
+
+def tail_frames(x, count):
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return to_nhwc(x)[x.shape[0] - count:]
+    return TailFramesFn.apply(x, count)
 
 
 class PPMConcatFn(torch.autograd.Function):
@@ -785,13 +965,17 @@ def softmax_channels(x):
     return ChannelSoftmaxFn.apply(x, False)
 
 
-def _labels_i64(label, n, H, W):
-    """[n,1,H,W] or [n,H,W] float/long labels -> contiguous int64 [n,H,W] (the reference's label.squeeze(1).long())."""
+def _labels(label, n, H, W):
+    """[n,1,H,W] or [n,H,W] labels -> (contiguous [n,H,W] tensor, is_float32).  fp32 labels - what the drivers hand
+    over - stay fp32: the loss kernels apply the reference's label.squeeze(1).long() themselves (no cast pass over
+    the label planes); anything else is converted to int64."""
     if label.dim() == 4:
         label = label.squeeze(1)
     if tuple(label.shape) != (n, H, W):
         raise RuntimeError("label shape %s does not match (%d,%d,%d)" % (tuple(label.shape), n, H, W))
-    return label.long().contiguous()
+    if label.dtype == torch.float32:
+        return label.contiguous(), 1
+    return label.long().contiguous(), 0
 
 
 class SegNLLFn(torch.autograd.Function):
@@ -804,7 +988,7 @@ class SegNLLFn(torch.autograd.Function):
         x = to_nhwc(x)
         n, k, h, w = x.shape
         H, W = label.shape[-2], label.shape[-1]
-        lab = _labels_i64(label, n, H, W)
+        lab, lab_f32 = _labels(label, n, H, W)
         st = _stream()
         if from_logits:
             logp = empty_nhwc(n, k, h, w, x.device)
@@ -813,11 +997,11 @@ class SegNLLFn(torch.autograd.Function):
             logp = x
         out = torch.empty(4, device=x.device, dtype=torch.float64)
         _C.call("vspw_zero_f64", _p(out), 4, st)
-        _C.call("vspw_seg_nll_fwd", _p(logp), _p(lab), _p(out), n, h, w, k, H, W, int(ignore_index),
+        _C.call("vspw_seg_nll_fwd", _p(logp), _p(lab), lab_f32, _p(out), n, h, w, k, H, W, int(ignore_index),
                 1 if want_acc else 0, st)
         loss = (out[0] * (1.0 / _NLL_FIXED) / out[1]).float()  # out[0] is fixed-point (include/vspw_hip.h)
         acc = (out[2] / (out[3] + 1e-10)).float()
-        ctx.meta = (n, k, h, w, H, W, int(ignore_index), bool(from_logits))
+        ctx.meta = (n, k, h, w, H, W, int(ignore_index), bool(from_logits), lab_f32)
         ctx.save_for_backward(logp, lab, out)
         ctx.mark_non_differentiable(acc)
         return loss, acc
@@ -825,10 +1009,10 @@ class SegNLLFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, gacc):
         logp, lab, out = ctx.saved_tensors
-        n, k, h, w, H, W, ignore, from_logits = ctx.meta
+        n, k, h, w, H, W, ignore, from_logits, lab_f32 = ctx.meta
         g = gloss.reshape(1).float().contiguous()
         dx = empty_nhwc(n, k, h, w, logp.device)
-        _C.call("vspw_seg_nll_bwd", _p(logp), _p(lab), _p(out), _p(g), _p(dx), n, h, w, k, H, W, ignore,
+        _C.call("vspw_seg_nll_bwd", _p(logp), _p(lab), lab_f32, _p(out), _p(g), _p(dx), n, h, w, k, H, W, ignore,
                 1 if from_logits else 0, _stream())
         return dx, None, None, None, None
 

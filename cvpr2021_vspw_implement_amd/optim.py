@@ -19,6 +19,12 @@ _ENTRY = np.dtype([("p", "<u8"), ("g", "<u8"), ("buf", "<u8"), ("n", "<i8"), ("c
                    ("wd", "<f4"), ("mult", "<i4"), ("first", "<i4"), ("lr_slot", "<i4"), ("reserved", "<i4")])
 
 
+def _same_element_order(a, b):
+    """Do two dense tensors of equal shape store their elements in the same order?  Strides of size-1 dimensions are
+    arbitrary (a [K,C,1,1] weight is both contiguous and channels_last), so only the others are compared."""
+    return a.shape == b.shape and all(sa == sb for n, sa, sb in zip(a.shape, a.stride(), b.stride()) if n != 1)
+
+
 class SGD(torch.optim.Optimizer):
     """torch.optim.SGD(momentum, weight_decay) of the pinned PyTorch 1.3.1 (README.md:13), duplicates included: a
     parameter listed k times in a group is updated k times per step, the weight-decay term accumulating in the
@@ -61,7 +67,7 @@ class SGD(torch.optim.Optimizer):
                 if not p.is_cuda:
                     raise RuntimeError("vspw SGD runs on the GPU only (no CPU fallback)")
                 g = p.grad
-                if g.stride() != p.stride():
+                if not _same_element_order(p, g):
                     g = torch.empty_like(p).copy_(g)
                 st = self.state[p]
                 if "momentum_buffer" not in st:
@@ -79,6 +85,9 @@ class SGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        from . import ops
+
+        ops.join_side_streams()  # weight gradients issued on the side stream
         by_mom = self._collect()
         if not by_mom:
             return loss
@@ -122,8 +131,6 @@ class SGD(torch.optim.Optimizer):
                     ctypes.c_void_p(self._lr_dev.data_ptr()),
                     ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
             self._keepalive = items  # until the next step: the launch is asynchronous
-        from . import ops
-
         ops.invalidate_inference_cache()  # folded conv+BN weights derive from the parameters just rewritten
         return loss
 

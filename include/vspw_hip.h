@@ -83,6 +83,16 @@ int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, const float
                            size_t ws_bytes, void* stream);
 /* [k][taps][c] -> [c][taps][k] */
 int vspw_weight_transpose(const float* w, float* wT, int k, int taps, int c, void* stream);
+/* The same transpose for many weight tensors in ONE launch.  `entries` is a DEVICE array sorted by tile0 (= the sum of
+ * vspw_weight_transpose_tiles() of all preceding entries); total_tiles = grid size. */
+typedef struct vspw_wt_entry {
+    const float* w; /* [k][taps][c] */
+    float* wT;      /* [c][taps][k] */
+    long long tile0;
+    int k, taps, c, reserved;
+} vspw_wt_entry;
+long long vspw_weight_transpose_tiles(int k, int taps, int c);
+int vspw_weight_transpose_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream);
 /* [n][c][hw] -> [n][hw][c]: the reference feeds NCHW images (train_clip2.py:45-47). */
 int vspw_nchw_to_nhwc(const float* in, float* out, int n, int c, long long hw, void* stream);
 
@@ -196,18 +206,19 @@ int vspw_softmax_pixels_fwd(const float* x, float* y, int b, int hw, int k, floa
 int vspw_softmax_pixels_bwd(const float* dy, const float* y, float* dx, int b, int hw, int k, float alpha,
                             void* stream);
 /* Fused  F.interpolate(logp,(H,W),bilinear) -> NLLLoss(ignore_index) -> pixel_acc  of models/clip_psp.py:198-216,
- * models/models.py:92-107.  logp [n][h][w][k] are log-probabilities at feature resolution; label [n][H][W] int64.
+ * models/models.py:92-107.  logp [n][h][w][k] are log-probabilities at feature resolution; label [n][H][W] is int64,
+ * or fp32 when label_f32 != 0 (the drivers hand over float labels; the kernel applies the reference's label.long()).
  * out[0]=VSPW_NLL_FIXED * sum of -logp_up[label] over non-ignored pixels (each workgroup's partial sum is rounded to a
  * multiple of 1/VSPW_NLL_FIXED, so the fp64 atomic accumulation adds integers and is bit-reproducible whatever the
  * order), out[1]=#non-ignored, out[2]=#(argmax==label), out[3]=#(label>=0) (fp64).  loss = out[0]/VSPW_NLL_FIXED/out[1].
  * out must be zeroed by the caller (vspw_zero_f64). */
 #define VSPW_NLL_FIXED 1048576.0
-int vspw_seg_nll_fwd(const float* logp, const int64_t* label, double* out, int n, int h, int w, int k, int H, int W,
-                     int ignore_index, int want_acc, void* stream);
+int vspw_seg_nll_fwd(const float* logp, const void* label, int label_f32, double* out, int n, int h, int w, int k,
+                     int H, int W, int ignore_index, int want_acc, void* stream);
 /* Gathers the bilinear adjoint of -gscale/count at the label channel into d(loss)/d(logp) [n][h][w][k]; with
  * lsm_jacobian != 0 it also applies the log-softmax Jacobian, i.e. returns d(loss)/d(logits) for
  * logp = log_softmax(logits).  gscale is a device scalar (the incoming gradient of the loss). */
-int vspw_seg_nll_bwd(const float* logp, const int64_t* label, const double* fwd_out, const float* gscale,
+int vspw_seg_nll_bwd(const float* logp, const void* label, int label_f32, const double* fwd_out, const float* gscale,
                      float* dlogits, int n, int h, int w, int k, int H, int W, int ignore_index, int lsm_jacobian,
                      void* stream);
 /* Inference head: probs[n][H][W][k] = softmax_k(bilinear(logits)) (models/clip_psp.py:190-194). */

@@ -51,7 +51,6 @@ struct IgemmNT {
     int vec;            // 1: float4 loads are legal (c % 4 == 0 and lds % 4 == 0)
     int lds;            // pixel stride of src in floats (c, or wider when src is a channel slice of a concat buffer)
     int act;            // epilogue activation: 0 none, 1 relu, 2 sigmoid, 3 tanh (inference-only entry point)
-    int stagger;        // first-round phase stagger (see igemm_nt_v2_kernel), in units of 64*127 cycles per residency slot
 };
 
 __device__ __forceinline__ float nt_act(float v, int act) {
@@ -335,17 +334,6 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
     const int tile_m = vb / tiles_n;
     const int m0 = tile_m * TM, n0 = tile_n * TN;
 
-    // Phase stagger.  All workgroups of the first residency round start together, so the 3-4 workgroups sharing a CU
-    // run in lockstep: they compete for the MFMA pipe during their K loops and then all sit in their (memory-bound)
-    // epilogues at the same time, with the pipe idle.  Delaying the k-th co-resident workgroup by k/(slots) of a tile
-    // time makes one workgroup's epilogue / prologue coincide with the others' K loops for the rest of the launch.
-    // (Which workgroups share a CU is inferred from the observed dispatch order - blockIdx round-robin over the 256
-    // CUs - and only affects speed.)
-    if (p.stagger > 0 && blockIdx.x < 1024) {
-        const int slot = blockIdx.x >> 8;
-        for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-
     const int lrow = tid >> 3;
     const int lcol = (tid & 7) * 4;
 
@@ -354,14 +342,25 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
     const int img0 = m0 / ohw;
     const char* src0 = reinterpret_cast<const char*>(p.src + (size_t)img0 * p.h * p.w * p.lds);
     const char* wt0 = reinterpret_cast<const char*>(p.wt + (size_t)n0 * p.kdim);
+    // Operand loads are RAW BUFFER loads (base in a scalar descriptor, 32-bit byte offset per lane, channel / k base as
+    // the scalar offset): the hardware bounds check returns 0 for an offset >= num_records, so a padding tap is just
+    // an out-of-range offset (NT_OOR) - no select on the loaded data.  That matters here more than anywhere: fp32 MFMA
+    // runs on the SIMD's f32 vector lanes, so every VALU instruction in the K loop is taken out of MFMA issue time
+    // (measured: the 12 v_cndmask + 6 v_and/v_cmp per K-tile of the select form cost 4-6 % on every 3x3 shape).
+    constexpr unsigned NT_OOR = 0x80000000u;
+    const long long a_rem = (long long)(p.nb - img0) * p.h * p.w * p.lds * 4;
+    const long long b_rem = (long long)(p.nout - n0) * p.kdim * 4;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(src0), 0, (int)(unsigned)(a_rem < (long long)NT_OOR ? a_rem : (long long)NT_OOR), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(wt0), 0, (int)(unsigned)(b_rem < (long long)NT_OOR ? b_rem : (long long)NT_OOR), 0x00020000);
     // MODE 2 = pointwise at compile time (1x1, stride 1, no padding: source pixel == output pixel, every tap in the
     // image): no tap state, no in-image bits, no selects - the K loop is a plain GEMM loop
     constexpr bool PW = MODE == 2;
     const bool pointwise = PW || ((p.kh * p.kw == 1) & (p.stride == 1) & (p.pad == 0) & (p.padw == 0));
 
     int a_base[RA], a_by[RA], a_bx[RA];
-    unsigned a_voff[RA];    // byte offset (from src0) of this row's source pixel for the current tap, + lcol
-    unsigned a_okbits = 0;  // bit i: that pixel is inside the image
+    unsigned a_voff[RA];    // byte offset (from src0) of this row's source pixel for the current tap, + lcol; NT_OOR = pad
     if (pointwise) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -369,7 +368,6 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
             a_voff[i] = (unsigned)(m * p.lds + lcol) * 4u;
             a_base[i] = a_by[i] = a_bx[i] = 0;
         }
-        a_okbits = (1u << RA) - 1u;
     } else {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
@@ -390,7 +388,6 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
     }
     const int sgn = (MODE == 0) ? p.dil : -p.dil;
     auto set_tap = [&](int ky, int kx) {
-        a_okbits = 0;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             int sy = a_by[i] + sgn * ky;
@@ -404,9 +401,8 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
                 sx = sx >= 0 ? sx / p.stride : -1;
             }
             ok = ok & ((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w);
-            const int syc = min(max(sy, 0), p.h - 1), sxc = min(max(sx, 0), p.w - 1);
-            a_voff[i] = (unsigned)(((a_base[i] + syc) * p.w + sxc) * p.lds + lcol) * 4u;
-            a_okbits |= ok ? (1u << i) : 0u;
+            const unsigned off = (unsigned)(((a_base[i] + sy) * p.w + sx) * p.lds + lcol) * 4u;
+            a_voff[i] = ok ? off : NT_OOR;
         }
     };
     if (!pointwise) set_tap(0, 0);
@@ -431,24 +427,20 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
         }
     };
     f32x4 ra[RA], rb[RB];
-    unsigned ok_regs = 0;  // in-image bits of the tile currently held in ra[]
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     auto load_tile = [&]() {
         if (more) {
-            const char* sa = src0 + (size_t)cb * 4;
-            const char* sb = wt0 + (size_t)kb * 4;
 #pragma unroll
-            for (int i = 0; i < RA; ++i) ra[i] = *reinterpret_cast<const f32x4*>(sa + a_voff[i]);
+            for (int i = 0; i < RA; ++i)
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[i], cb * 4, 0));
 #pragma unroll
-            for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(sb + b_voff[i]);
-            ok_regs = a_okbits;
+            for (int i = 0; i < RB; ++i)
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff[i], kb * 4, 0));
         }
     };
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto store_tile = [&](float* Ad, float* Bd) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i)
-            *reinterpret_cast<f32x4*>(&Ad[(lrow + 32 * i) * LDA + lcol]) =
-                (PW || ((ok_regs >> i) & 1u)) ? ra[i] : zero4;
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&Ad[(lrow + 32 * i) * LDA + lcol]) = ra[i];
 #pragma unroll
         for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(&Bd[(lrow + 32 * i) * LDA + lcol]) = rb[i];
     };
@@ -712,7 +704,8 @@ static int nt_decide(const IgemmNT& p, bool& v2) {
     // 32-bit byte offsets relative to the first image a tile touches / the tile's first weight row
     const long long img_elems = (long long)p.h * p.w * p.lds;
     const long long span = (128 / ((long long)p.oh * p.ow) + 2) * img_elems;
-    v2 = p.vec && p.c % BK == 0 && span < (1LL << 30) && (long long)p.kdim < (1LL << 22) &&
+    // byte offsets (incl. the scalar channel / k base) must stay below the 2 GiB out-of-range marker of the buffer loads
+    v2 = p.vec && p.c % BK == 0 && span < (1LL << 28) && (long long)p.kdim < (1LL << 21) &&
          true;  // forward (any stride) and data gradient (any stride: inexact taps are masked per tap)
     if (!v2 && cfg == 31) cfg = 12;  // the generic kernel has no 96-row instantiation
     return cfg;
@@ -1286,11 +1279,6 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restr
     }
 }
 
-static int nt_stagger() {
-    static const int v = getenv("VSPW_STAGGER") ? atoi(getenv("VSPW_STAGGER")) : 0;
-    return v;
-}
-
 static int conv_geometry_ok(const vspw_conv_desc* d) {
     if (!d) return 0;
     if (d->n <= 0 || d->h <= 0 || d->w <= 0 || d->c <= 0 || d->k <= 0) return 0;
@@ -1315,7 +1303,6 @@ static bool fill_fwd_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.vec = (d->c % 4 == 0) ? 1 : 0;
     p.lds = d->c;
     p.act = 0;
-    p.stagger = nt_stagger();
     return true;
 }
 
@@ -1409,7 +1396,6 @@ static bool fill_bwd_data_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.vec = (d->k % 4 == 0) ? 1 : 0;
     p.lds = d->k;
     p.act = 0;
-    p.stagger = nt_stagger();
     return true;
 }
 

@@ -911,6 +911,8 @@ template <int G, int NBUF, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     constexpr bool LIN = G >= 2;
     constexpr bool WIDE = G >= 1;
+    constexpr bool UNI = G == 4;  // linear + tap uniform per workgroup + rows uniform per half-wave: scalar validity
+    constexpr bool TAPS = G == 2 || G == 4;
     constexpr int TM = 64 * WM, TN = 64 * WN;
     constexpr int A4 = TM / 4, B4 = TN / 4;          // float4 per staged row
     constexpr int RPA = 256 / A4, RPB = 256 / B4;    // rows covered per pass
@@ -940,6 +942,11 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
 
     const int krow_a = tid / A4, ca4 = (tid % A4) * 4;
     const int krow_b = tid / B4, cb4 = (tid % B4) * 4;
+    // UNI (TN = 128: one staged row = one half-wave): wave v stages rows 8v .. 8v+7, pass i rows 8v+2i (lanes 0-31) and
+    // 8v+2i+1 (lanes 32-63) - the pixel of a staged row is then wave-uniform and its in-image test runs on the SCALAR
+    // unit (the K loop keeps one v_cndmask per pass on the vector ALU)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto brow = [&](int i) { return UNI ? wave_u * 8 + 2 * i + lh : krow_b + RPB * i; };
 
     // this thread's A column (co) and B column (tap, ci): fixed for the whole kernel.  The linear modes clamp them to
     // the last valid float4 instead of masking: rows / columns of dW past the matrix are computed and never stored.
@@ -964,7 +971,17 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     // the linear pixel index.
     int pk0 = p_begin;
     int r_n[PB], r_oy[PB], r_ox[PB];
-    if (G != 3) {
+    int su_oy = 0, su_ox = 0, su_dy = 0, su_dx = 0;  // UNI: (oy, ox) of pixel pk0 + 8*wave, tap displacement (scalars)
+    if (UNI) {
+        const int tap = __builtin_amdgcn_readfirstlane(n0 / p.c);
+        const int ky = tap / p.kw;
+        su_dy = ky * p.dil - p.pad;
+        su_dx = (tap - ky * p.kw) * p.dil - p.padw;
+        const int r = (p_begin + wave_u * 8) % ohw;
+        su_oy = r / p.ow;
+        su_ox = r - su_oy * p.ow;
+    }
+    if (G != 3 && !UNI) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             const int pp = p_begin + krow_b + RPB * i;
@@ -980,14 +997,15 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     const char* dyb = reinterpret_cast<const char*>(p.dy) + (size_t)p_begin * p.k * 4;
     const char* xb = reinterpret_cast<const char*>(p.x) + ((long long)p_begin - p.pad * p.w - p.padw) * p.c * 4;
     unsigned a_voff[PA], b_voff[PB];
-    const unsigned a_safe = (unsigned)co * 4u;                                      // row 0 of the tile, same column
-    const unsigned b_safe = (unsigned)((p.pad * p.w + p.padw) * p.c + b_ci) * 4u;    // centre tap of row 0
+    // pixels from xb to the last staged pixel's farthest tap, minus the staged pixels themselves: 2*pad rows + 2*padw
+    // pixels (every tap offset lies in [0, 2*(pad*w + padw)] pixels)
+    const int tap_px = 2 * (p.pad * p.w + p.padw);
     if (LIN) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) a_voff[i] = (unsigned)((krow_a + RPA * i) * p.k + co) * 4u;
         const int tapoff = ((b_dy + p.pad) * p.w + (b_dx + p.padw)) * p.c + b_ci;
 #pragma unroll
-        for (int i = 0; i < PB; ++i) b_voff[i] = (unsigned)((krow_b + RPB * i) * p.c + tapoff) * 4u;
+        for (int i = 0; i < PB; ++i) b_voff[i] = (unsigned)(brow(i) * p.c + tapoff) * 4u;
     }
     auto advance = [&]() {
         pk0 += BK;
@@ -996,6 +1014,14 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
             xb += (size_t)BK * p.c * 4;
         }
         if (G == 3) return;
+        if (UNI) {  // scalar: ow >= BK, at most one row wrap per step
+            su_ox += BK;
+            if (su_ox >= p.ow) {
+                su_ox -= p.ow;
+                su_oy = (su_oy + 1 >= p.oh) ? 0 : su_oy + 1;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             if (WIDE) {  // ow >= BK: at most one row wrap per step
@@ -1017,23 +1043,58 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     };
     f32x4 ra[PA], rb[PB];
     bool oka[PA], okb[PB];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr unsigned TN_OOR = 0x80000000u;
     auto load_tile = [&]() {
         if (LIN) {
+            // Raw buffer loads: the descriptors are rebuilt per K-tile from scalars (base = first pixel of the tile,
+            // num_records = bytes left in this workgroup's pixel chunk), so rows past the chunk are out of range and
+            // come back as zeros from the hardware bounds check; an out-of-image 3x3 tap is the out-of-range offset
+            // TN_OOR.  No select touches the loaded data and no address arithmetic runs on the vector ALU - which
+            // matters because fp32 MFMA executes on the SIMD's f32 vector lanes: VALU instructions in this loop are
+            // subtracted from MFMA issue time (the select form spent 45 / 89 VALU instructions per 64 MFMAs).
             const int rows_left = p_end - pk0;  // uniform
             if (rows_left <= 0) return;         // prefetch past the chunk: nothing to fetch, registers never consumed
+            const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(dyb), 0, rows_left * p.k * 4, 0x00020000);
 #pragma unroll
-            for (int i = 0; i < PA; ++i) {
-                oka[i] = (krow_a + RPA * i) < rows_left;
-                ra[i] = *reinterpret_cast<const f32x4*>(dyb + (oka[i] ? a_voff[i] : a_safe));
-            }
+            for (int i = 0; i < PA; ++i)
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[i], 0, 0));
+            // x: the tile's rows start (pad rows + pad pixels) before its first pixel (xb), so the chunk's last pixel
+            // with the largest tap offset ends tap_px pixels after rows_left pixels
+            // (never past the end of x: the last chunk's rows beyond P are out of range and read as zeros; an interior
+            // chunk's rows beyond rows_left are masked below - a uniform branch taken only in a chunk's last K-tile)
+            const int x_left_px = p.P - (pk0 - tap_px / 2);  // pixels from xb to the end of x (scalar)
+            const int want_px = rows_left + tap_px;
+            const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(xb), 0, (want_px < x_left_px ? want_px : x_left_px) * p.c * 4, 0x00020000);
 #pragma unroll
             for (int i = 0; i < PB; ++i) {
-                okb[i] = (krow_b + RPB * i) < rows_left;
-                if (G == 2) {
-                    const int sy = r_oy[i] + b_dy, sx = r_ox[i] + b_dx;
-                    okb[i] = okb[i] & ((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w);
+                unsigned off = b_voff[i];
+                if (UNI) {
+                    unsigned kill[2];  // 0 or TN_OOR per half-wave row, computed on the scalar unit
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {  // rows 8*wave + 2i + e
+                        const int j = 2 * i + e;
+                        int x = su_ox + j, y = su_oy;
+                        if (x >= p.ow) {
+                            x -= p.ow;
+                            y = (y + 1 >= p.oh) ? 0 : y + 1;
+                        }
+                        const bool ok = ((unsigned)(y + su_dy) < (unsigned)p.h) & ((unsigned)(x + su_dx) < (unsigned)p.w) &
+                                        (wave_u * 8 + j < rows_left);
+                        kill[e] = ok ? 0u : TN_OOR;
+                    }
+                    off |= lh ? kill[1] : kill[0];  // valid offsets are < 2 GiB: the top bit makes them out of range
+                } else {
+                    if (G == 2) {
+                        const int sy = r_oy[i] + b_dy, sx = r_ox[i] + b_dx;
+                        off = (((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w)) ? off : TN_OOR;
+                        // interior chunks: rows past rows_left would read real pixels (times a zero dY row)
+                        off = (krow_b + RPB * i < rows_left) ? off : TN_OOR;
+                    }
                 }
-                rb[i] = *reinterpret_cast<const f32x4*>(xb + (okb[i] ? b_voff[i] : b_safe));
+                rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, off, 0, 0));
             }
             return;
         }
@@ -1055,10 +1116,10 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     auto store_tile = [&](float* Ad, float* Bd) {
 #pragma unroll
         for (int i = 0; i < PA; ++i)
-            *reinterpret_cast<f32x4*>(&Ad[(krow_a + RPA * i) * TM + ca4]) = oka[i] ? ra[i] : zero4;
+            *reinterpret_cast<f32x4*>(&Ad[(krow_a + RPA * i) * TM + ca4]) = (LIN || oka[i]) ? ra[i] : zero4;
 #pragma unroll
         for (int i = 0; i < PB; ++i)
-            *reinterpret_cast<f32x4*>(&Bd[(krow_b + RPB * i) * TN + cb4]) = okb[i] ? rb[i] : zero4;
+            *reinterpret_cast<f32x4*>(&Bd[brow(i) * TN + cb4]) = (LIN || okb[i]) ? rb[i] : zero4;
     };
 
     f32x16 acc[WM][WN];
@@ -1478,7 +1539,8 @@ extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, 
         // gather mode (see igemm_tn_v2_kernel)
         const bool same = d->stride == 1 && d->oh == d->h && d->ow == d->w;
         const bool point = same && d->kh * d->kw == 1 && d->pad == 0 && d->pad_w == 0;
-        const int g = point ? 3 : (same && p.ow >= BK) ? 2 : (p.ow >= BK ? 1 : 0);
+        // 4: linear gather whose 128-column tiles never straddle a filter tap (Cin % 128 == 0): scalar in-image tests
+        const int g = point ? 3 : (same && p.ow >= BK) ? ((tn == 128 && d->c % 128 == 0) ? 4 : 2) : (p.ow >= BK ? 1 : 0);
         const int code = g * 100 + (tm / 64) * 10 + (tn / 64);
 #define TN_CASE(G, NB, WM_, WN_) \
     case G * 100 + WM_ * 10 + WN_: \
@@ -1489,6 +1551,7 @@ extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, 
             TN_CASE(1, TN_NBUF, 2, 2) TN_CASE(1, 1, 1, 2) TN_CASE(1, 1, 2, 1) TN_CASE(1, 1, 1, 1)
             TN_CASE(2, TN_NBUF, 2, 2) TN_CASE(2, 1, 1, 2) TN_CASE(2, 1, 2, 1) TN_CASE(2, 1, 1, 1)
             TN_CASE(3, TN_NBUF, 2, 2) TN_CASE(3, 1, 1, 2) TN_CASE(3, 1, 2, 1) TN_CASE(3, 1, 1, 1)
+            TN_CASE(4, TN_NBUF, 2, 2) TN_CASE(4, 1, 1, 2)
             default: return VSPW_EINVAL;
         }
 #undef TN_CASE

@@ -304,18 +304,26 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
 // the uniform (scalar-branch) "tap changed" refresh every Cin/32 iterations.  Measured on the GEMM probe
 // (tools/probe/mfma_ablate.hip): VALU work in the loop is not hidden behind the fp32 MFMAs, it is added to them.
 //   * NBUF 2: two LDS buffers, ONE barrier per K-tile; NBUF 1: one buffer, two barriers, half the LDS (residency).
-//   * zeroing of out-of-image taps is a select applied when the registers are written to LDS (one K-tile later), so
-//     no vmcnt wait is forced near the load; rows >= M and columns >= Cout read clamped (valid) addresses and are
-//     simply never stored.
+//   * operands arrive through raw buffer loads: an out-of-image tap is an out-of-range offset that the hardware bounds
+//     check turns into zeros (no select on the data); rows >= M and columns >= Cout read clamped (valid) addresses and
+//     are simply never stored.  The K loops contain NO vector-ALU instruction: fp32 MFMA executes on the SIMD's f32
+//     vector lanes, so VALU work in the loop is not hidden behind the MFMAs, it is subtracted from them.
 // MODE 0: forward gather (any stride);  MODE 1: data-gradient gather (any stride);  MODE 2: pointwise.
 // WGM = waves along M (2: 2x2 waves, 1: 1x4 waves); workgroup tile = (32*WM*WGM) x (32*WN*(4/WGM)).
 // Register budget: tiles with <= 48 accumulator registers per lane are compiled for 4 waves per SIMD (<= 128 unified
 // registers, accumulators in VGPRs, no spills - checked with -Rpass-analysis=kernel-resource-usage); the 128x128 tile
 // (64 accumulators) would spill under that cap and stays at 3.  Measured: +1 % on the 3x3 shapes; the pointwise
 // shapes lose 4-5 % with the fourth wave (more L2 pressure per CU), so MODE 2 stays at 3 as well.
-template <int WGM, int WM, int WN, int MODE, int NBUF>
-__global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 : (NBUF == 1 ? 3 : 2)) void igemm_nt_v2_kernel(
+// TAPS = 9: K order "channel slab outer, filter tap inner" for 3x3 filters.  In the default order (tap outer) the tiles
+// resident on one XCD sweep their whole input window once per tap - ~4.7 MB for the layer3 shapes, just over the 4 MB
+// L2, so every tap pass re-fetched it from the Infinity Cache (measured 261 MB fetched for 39 MB of operands).  With
+// the tap inside, one 32-channel slab of the window (1/8 of it) is reused by all nine taps while it sits in L2.  The
+// nine per-tap offsets of each staged row are computed ONCE (9*RA registers, hence 3 waves per SIMD), the K loop is
+// unrolled over the taps, and nothing is left of the per-tap refresh: its K loop has no VALU instruction at all.
+template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0>
+__global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAPS == 0) ? 4 : (NBUF == 1 ? 3 : 2)) void igemm_nt_v2_kernel(
     IgemmNT p) {
+    static_assert(TAPS == 0 || (NBUF == 1 && MODE != 2), "tap-inner order: single LDS buffer, non-pointwise");
     constexpr int WGN = 4 / WGM;
     constexpr int TM = 32 * WM * WGM, TN = 32 * WN * WGN;
     constexpr int RA = TM / 32, RB = TN / 32;
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
         }
     }
     const int sgn = (MODE == 0) ? p.dil : -p.dil;
-    auto set_tap = [&](int ky, int kx) {
+    auto tap_offsets = [&](int ky, int kx, unsigned* out) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             int sy = a_by[i] + sgn * ky;
@@ -402,9 +410,10 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
             }
             ok = ok & ((unsigned)sy < (unsigned)p.h) & ((unsigned)sx < (unsigned)p.w);
             const unsigned off = (unsigned)(((a_base[i] + sy) * p.w + sx) * p.lds + lcol) * 4u;
-            a_voff[i] = ok ? off : NT_OOR;
+            out[i] = ok ? off : NT_OOR;
         }
     };
+    auto set_tap = [&](int ky, int kx) { tap_offsets(ky, kx, a_voff); };
     if (!pointwise) set_tap(0, 0);
     unsigned b_voff[RB];
 #pragma unroll
@@ -471,6 +480,56 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
 
+    if constexpr (TAPS > 0) {
+        // ---- channel-slab-outer / tap-inner K loop (see the template comment) ----
+        unsigned a_toff[TAPS][RA];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) tap_offsets(t / 3, t % 3, a_toff[t]);
+        const int nslab = p.c / BK;
+        auto load_kt = [&](int t, int cs) {  // t is a compile-time constant at every call site
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_toff[t][i], cs * (BK * 4), 0));
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                rb[i] = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff[i], (t * p.c + cs * BK) * 4, 0));
+        };
+        load_kt(0, 0);
+        for (int cs = 0; cs < nslab; ++cs) {
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                store_tile(As[0], Bs[0]);
+                __syncthreads();
+                const float* Ac = As[0];
+                const float* Bc = Bs[0];
+#pragma unroll
+                for (int kc = 0; kc < BK / 8; ++kc) {
+                    f32x4 fa[WM], fb[WN];
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+                        fa[i] = *reinterpret_cast<const f32x4*>(&Ac[(wm * 32 * WM + i * 32 + l31) * LDA + kc * 8 + 4 * lh]);
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        fb[j] = *reinterpret_cast<const f32x4*>(&Bc[(wn * 32 * WN + j * 32 + l31) * LDA + kc * 8 + 4 * lh]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < WM; ++i)
+#pragma unroll
+                            for (int j = 0; j < WN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+                    if (kc == 0) {  // next K-tile: next tap of this slab, or tap 0 of the next slab
+                        if (t + 1 < TAPS)
+                            load_kt(t + 1 < TAPS ? t + 1 : 0, cs);
+                        else if (cs + 1 < nslab)
+                            load_kt(0, cs + 1);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    } else {
     const int nk = p.kdim / BK;
     // prologue: tile 0 -> LDS[0]; tile 1 -> registers
     load_tile();
@@ -490,17 +549,28 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
         }
         const float* Ac = As[cur];
         const float* Bc = Bs[cur];
-#pragma unroll
-        for (int kc = 0; kc < BK / 8; ++kc) {
-            f32x4 a[WM], b[WN];
+        // fragments of k-group kc+1 are fetched while group kc's MFMAs issue (VSPW_FRAG_PREFETCH): the wave never sits
+        // in an LDS-latency wait between groups
+        f32x4 fa[2][WM], fb[2][WN];
+        auto load_frag = [&](int kc, int slot) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(&Ac[(wm * 32 * WM + i * 32 + l31) * LDA + kc * 8 + 4 * lh]);
+                fa[slot][i] = *reinterpret_cast<const f32x4*>(&Ac[(wm * 32 * WM + i * 32 + l31) * LDA + kc * 8 + 4 * lh]);
 #pragma unroll
             for (int j = 0; j < WN; ++j)
-                b[j] = *reinterpret_cast<const f32x4*>(&Bc[(wn * 32 * WN + j * 32 + l31) * LDA + kc * 8 + 4 * lh]);
-#ifdef VSPW_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
+                fb[slot][j] = *reinterpret_cast<const f32x4*>(&Bc[(wn * 32 * WN + j * 32 + l31) * LDA + kc * 8 + 4 * lh]);
+        };
+#ifdef VSPW_FRAG_PREFETCH
+        load_frag(0, 0);
+#endif
+#pragma unroll
+        for (int kc = 0; kc < BK / 8; ++kc) {
+#ifdef VSPW_FRAG_PREFETCH
+            if (kc + 1 < BK / 8) load_frag(kc + 1, (kc + 1) & 1);
+            const int sl = kc & 1;
+#else
+            load_frag(kc, 0);
+            const int sl = 0;
 #endif
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -508,10 +578,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-#ifdef VSPW_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sl][i][s], fb[sl][j][s], acc[i][j], 0, 0, 0);
             if (kc == 0) {
                 if (NBUF == 2) {
                     // tile kt+1 has been in flight since the middle of the previous iteration: registers -> the
@@ -525,6 +592,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2) ? 4 :
         }
         __syncthreads();
     }
+    }  // tap-outer order
 
     float csum[WN], csq[WN];
     if (interior) {
@@ -671,6 +739,28 @@ static int nt_tile_rows(int cfg) { return (cfg == 22 || cfg == 21) ? 128 : (cfg 
 
 template <int MODE>
 static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
+    if constexpr (MODE != 2) {
+        static const int tap_inner = getenv("VSPW_TAP_INNER") ? atoi(getenv("VSPW_TAP_INNER")) : 1;
+        if (tap_inner && p.kh == 3 && p.kw == 3) {  // 3x3: channel-slab-outer / tap-inner K order
+            if (cfg == 22) {
+                int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 1, 9>), dim3(tiles), dim3(256), 0, st, p);
+            } else if (cfg == 31) {
+                int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, MODE, 1, 9>), dim3(tiles), dim3(256), 0, st, p);
+            } else if (cfg == 12) {
+                int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, MODE, 1, 9>), dim3(tiles), dim3(256), 0, st, p);
+            } else if (cfg == 21) {
+                int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, MODE, 1, 9>), dim3(tiles), dim3(256), 0, st, p);
+            } else {
+                int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, MODE, 1, 9>), dim3(tiles), dim3(256), 0, st, p);
+            }
+            return;
+        }
+    }
     if (cfg == 22) {
         int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
         // measured: short reductions (K <= 1024, i.e. the 1x1 convs) gain ~10 % from the higher residency of the

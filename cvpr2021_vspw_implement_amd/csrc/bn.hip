@@ -608,3 +608,35 @@ extern "C" int vspw_bn_bwd_apply(const float* dz, const float* z, const float* x
                            dgamma, dbeta, c);
     return vspw_launch_status();
 }
+
+// Coefficients of BatchNorm's backward "apply" as an affine map of (g, y) per channel:
+//   dy = a*(g - mg - xhat*mgx),  xhat = (y - mu)*is,  a = gamma*is,  mg = sum(g)/count,  mgx = sum(g*xhat)/count
+//      = coef[0]*g + coef[1]*y + coef[2]      with coef[0] = a, coef[1] = -a*is*mgx, coef[2] = a*(mu*is*mgx - mg)
+// evaluated in fp64 and rounded once.  Consumed by the affine-operand GEMMs (vspw_conv2d_bwd_data_aff /
+// vspw_conv2d_bwd_weight_aff), which therefore never need dy in memory.  training == 0: dy = a*g.
+__global__ void bn_bwd_affine_coeffs_kernel(const double* __restrict__ sums, double inv_count,
+                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                            const float* __restrict__ invstd, float* __restrict__ coef, int c,
+                                            int training) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c) return;
+    const double is = invstd[i];
+    const double a = (gamma ? (double)gamma[i] : 1.0) * is;
+    double b = 0.0, k = 0.0;
+    if (training) {
+        const double mg = sums[i] * inv_count, mgx = sums[c + i] * inv_count;
+        b = -a * is * mgx;
+        k = a * ((double)mean[i] * is * mgx - mg);
+    }
+    coef[i] = (float)a;
+    coef[c + i] = (float)b;
+    coef[2 * c + i] = (float)k;
+}
+
+extern "C" int vspw_bn_bwd_affine_coeffs(const double* sums, double count, const float* gamma, const float* mean,
+                                         const float* invstd, float* coef, int c, int training, void* stream) {
+    if (!sums || !mean || !invstd || !coef || c <= 0 || count <= 0) return VSPW_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_affine_coeffs_kernel, dim3(vspw_cdiv(c, 256)), dim3(256), 0, vspw_stream(stream), sums,
+                       1.0 / count, gamma, mean, invstd, coef, c, training);
+    return vspw_launch_status();
+}

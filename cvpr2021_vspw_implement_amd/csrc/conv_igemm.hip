@@ -51,6 +51,12 @@ struct IgemmNT {
     int vec;            // 1: float4 loads are legal (c % 4 == 0 and lds % 4 == 0)
     int lds;            // pixel stride of src in floats (c, or wider when src is a channel slice of a concat buffer)
     int act;            // epilogue activation: 0 none, 1 relu, 2 sigmoid, 3 tanh (inference-only entry point)
+    // Affine A operand (pointwise data gradient only): the GEMM's A element is coef[0][k]*src + coef[1][k]*src2 + coef[2][k]
+    // - BatchNorm's backward "apply" (dy = a*(g - mean(g) - xhat*mean(g*xhat))) evaluated while the operand is staged,
+    // so that dy (the gradient w.r.t. the conv output) is never written to / re-read from memory.  src = g, src2 = the
+    // node's pre-BN activations y; coef [3][kdim] from vspw_bn_bwd_affine_coeffs.
+    const float* src2;
+    const float* coef;
 };
 
 __device__ __forceinline__ float nt_act(float v, int act) {
@@ -320,10 +326,11 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
 // the tap inside, one 32-channel slab of the window (1/8 of it) is reused by all nine taps while it sits in L2.  The
 // nine per-tap offsets of each staged row are computed ONCE (9*RA registers, hence 3 waves per SIMD), the K loop is
 // unrolled over the taps, and nothing is left of the per-tap refresh: its K loop has no VALU instruction at all.
-template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0>
-__global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAPS == 0) ? 4 : (NBUF == 1 ? 3 : 2)) void igemm_nt_v2_kernel(
+template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, bool AFF = false>
+__global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAPS == 0) ? 4 : ((NBUF == 1 && !(AFF && WM * WN > 3)) ? 3 : 2)) void igemm_nt_v2_kernel(
     IgemmNT p) {
     static_assert(TAPS == 0 || (NBUF == 1 && MODE != 2), "tap-inner order: single LDS buffer, non-pointwise");
+    static_assert(!AFF || (MODE == 2 && NBUF == 1), "affine A operand: pointwise, single LDS buffer");
     constexpr int WGN = 4 / WGM;
     constexpr int TM = 32 * WM * WGM, TN = 32 * WN * WGN;
     constexpr int RA = TM / 32, RB = TN / 32;
@@ -362,6 +369,11 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
         const_cast<char*>(src0), 0, (int)(unsigned)(a_rem < (long long)NT_OOR ? a_rem : (long long)NT_OOR), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(wt0), 0, (int)(unsigned)(b_rem < (long long)NT_OOR ? b_rem : (long long)NT_OOR), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(AFF ? p.src2 + (size_t)img0 * p.h * p.w * p.lds : p.src)), 0,
+        (int)(unsigned)(a_rem < (long long)NT_OOR ? a_rem : (long long)NT_OOR), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(AFF ? p.coef : p.wt), 0, 3 * p.kdim * 4, 0x00020000);
     // MODE 2 = pointwise at compile time (1x1, stride 1, no padding: source pixel == output pixel, every tap in the
     // image): no tap state, no in-image bits, no selects - the K loop is a plain GEMM loop
     constexpr bool PW = MODE == 2;
@@ -436,18 +448,32 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
         }
     };
     f32x4 ra[RA], rb[RB];
+    f32x4 ra2[AFF ? RA : 1], cf[3];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     auto load_tile = [&]() {
         if (more) {
 #pragma unroll
             for (int i = 0; i < RA; ++i)
                 ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[i], cb * 4, 0));
+            if (AFF) {
+#pragma unroll
+                for (int i = 0; i < RA; ++i)
+                    ra2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a2, a_voff[i], cb * 4, 0));
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+                    cf[e] = __builtin_bit_cast(
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_c, (unsigned)(e * p.kdim + lcol) * 4u, kb * 4, 0));
+            }
 #pragma unroll
             for (int i = 0; i < RB; ++i)
                 rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, b_voff[i], kb * 4, 0));
         }
     };
     auto store_tile = [&](float* Ad, float* Bd) {
+        if (AFF) {  // the only vector-ALU work of this loop: 8 FMAs per staged float4
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[i] = cf[0] * ra[i] + (cf[1] * ra2[i] + cf[2]);
+        }
 #pragma unroll
         for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&Ad[(lrow + 32 * i) * LDA + lcol]) = ra[i];
 #pragma unroll
@@ -739,6 +765,27 @@ static int nt_tile_rows(int cfg) { return (cfg == 22 || cfg == 21) ? 128 : (cfg 
 
 template <int MODE>
 static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
+    if constexpr (MODE == 2) {
+        if (p.src2 != nullptr) {  // affine A operand (fused BatchNorm-backward apply)
+            if (cfg == 22) {
+                int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, 2, 1, 0, true>), dim3(tiles), dim3(256), 0, st, p);
+            } else if (cfg == 31) {
+                int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, 2, 1, 0, true>), dim3(tiles), dim3(256), 0, st, p);
+            } else if (cfg == 12) {
+                int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, 2, 1, 0, true>), dim3(tiles), dim3(256), 0, st, p);
+            } else if (cfg == 21) {
+                int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, 2, 1, 0, true>), dim3(tiles), dim3(256), 0, st, p);
+            } else {
+                int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, 2, 1, 0, true>), dim3(tiles), dim3(256), 0, st, p);
+            }
+            return;
+        }
+    }
     if constexpr (MODE != 2) {
         static const int tap_inner = getenv("VSPW_TAP_INNER") ? atoi(getenv("VSPW_TAP_INNER")) : 1;
         if (tap_inner && p.kh == 3 && p.kw == 3) {  // 3x3: channel-slab-outer / tap-inner K order
@@ -846,6 +893,9 @@ struct IgemmTN {
     int chunk;   // pixels per split (multiple of BK)
     int vec_a;   // k % 4 == 0
     int vec_b;   // c % 4 == 0
+    // gather mode 5 (pointwise + affine dY): dY element = coef[0][co]*dy + coef[1][co]*dy2 + coef[2][co]  (see IgemmNT)
+    const float* dy2;
+    const float* coef;
 };
 
 __global__ __launch_bounds__(256) void igemm_tn_kernel(IgemmTN p) {
@@ -1003,6 +1053,8 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     constexpr bool WIDE = G >= 1;
     constexpr bool UNI = G == 4;  // linear + tap uniform per workgroup + rows uniform per half-wave: scalar validity
     constexpr bool TAPS = G == 2 || G == 4;
+    constexpr bool PWG = G == 3 || G == 5;  // pointwise: no pixel coordinates at all
+    constexpr bool AFF = G == 5;            // pointwise + affine dY operand (every pixel chunk is a multiple of BK)
     constexpr int TM = 64 * WM, TN = 64 * WN;
     constexpr int A4 = TM / 4, B4 = TN / 4;          // float4 per staged row
     constexpr int RPA = 256 / A4, RPB = 256 / B4;    // rows covered per pass
@@ -1071,7 +1123,7 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
         su_oy = r / p.ow;
         su_ox = r - su_oy * p.ow;
     }
-    if (G != 3 && !UNI) {
+    if (!PWG && !UNI) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             const int pp = p_begin + krow_b + RPB * i;
@@ -1085,6 +1137,13 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     // pixels) before the tile's first pixel so that every tap offset is non-negative; it is only dereferenced with
     // offsets that land inside the tensor.
     const char* dyb = reinterpret_cast<const char*>(p.dy) + (size_t)p_begin * p.k * 4;
+    const char* dyb2 = reinterpret_cast<const char*>(AFF ? p.dy2 : p.dy) + (size_t)p_begin * p.k * 4;
+    f32x4 cfa = {1.f, 1.f, 1.f, 1.f}, cfb = {0.f, 0.f, 0.f, 0.f}, cfc = cfb;  // this thread's dY columns never change
+    if (AFF) {
+        cfa = *reinterpret_cast<const f32x4*>(p.coef + co);
+        cfb = *reinterpret_cast<const f32x4*>(p.coef + p.k + co);
+        cfc = *reinterpret_cast<const f32x4*>(p.coef + 2 * p.k + co);
+    }
     const char* xb = reinterpret_cast<const char*>(p.x) + ((long long)p_begin - p.pad * p.w - p.padw) * p.c * 4;
     unsigned a_voff[PA], b_voff[PB];
     // pixels from xb to the last staged pixel's farthest tap, minus the staged pixels themselves: 2*pad rows + 2*padw
@@ -1103,7 +1162,8 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
             dyb += (size_t)BK * p.k * 4;
             xb += (size_t)BK * p.c * 4;
         }
-        if (G == 3) return;
+        if (AFF) dyb2 += (size_t)BK * p.k * 4;
+        if (PWG) return;
         if (UNI) {  // scalar: ow >= BK, at most one row wrap per step
             su_ox += BK;
             if (su_ox >= p.ow) {
@@ -1131,7 +1191,7 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
             }
         }
     };
-    f32x4 ra[PA], rb[PB];
+    f32x4 ra[PA], rb[PB], ra2[AFF ? PA : 1];
     bool oka[PA], okb[PB];
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     constexpr unsigned TN_OOR = 0x80000000u;
@@ -1150,6 +1210,13 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
 #pragma unroll
             for (int i = 0; i < PA; ++i)
                 ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[i], 0, 0));
+            if (AFF) {
+                const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<char*>(dyb2), 0, rows_left * p.k * 4, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < PA; ++i)
+                    ra2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a2, a_voff[i], 0, 0));
+            }
             // x: the tile's rows start (pad rows + pad pixels) before its first pixel (xb), so the chunk's last pixel
             // with the largest tap offset ends tap_px pixels after rows_left pixels
             // (never past the end of x: the last chunk's rows beyond P are out of range and read as zeros; an interior
@@ -1204,6 +1271,10 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
     };
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     auto store_tile = [&](float* Ad, float* Bd) {
+        if (AFF) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) ra[i] = cfa * ra[i] + (cfb * ra2[i] + cfc);
+        }
 #pragma unroll
         for (int i = 0; i < PA; ++i)
             *reinterpret_cast<f32x4*>(&Ad[(krow_a + RPA * i) * TM + ca4]) = (LIN || oka[i]) ? ra[i] : zero4;
@@ -1442,6 +1513,7 @@ static int conv_geometry_ok(const vspw_conv_desc* d) {
 static bool fill_fwd_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr; p.addend = nullptr;
     p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
+    p.src2 = nullptr; p.coef = nullptr;
     p.nb = d->n; p.h = d->h; p.w = d->w; p.c = d->c;
     p.oh = d->oh; p.ow = d->ow;
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;
@@ -1498,8 +1570,12 @@ struct BnFront {
     const float* bn_invstd;
     float* stat_part;
 };
+struct AffA {
+    const float* y;
+    const float* coef;
+};
 static int conv2d_bwd_data_impl(const vspw_conv_desc* d, const float* dy, const float* wT, const float* addend,
-                                float* dx, void* stream, const BnFront* bn = nullptr);
+                                float* dx, void* stream, const BnFront* bn = nullptr, const AffA* aff = nullptr);
 static bool fill_bwd_data_params(const vspw_conv_desc* d, IgemmNT& p);
 
 extern "C" int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, const float* wT, float* dx,
@@ -1532,9 +1608,25 @@ extern "C" int vspw_conv2d_bwd_data_bn(const vspw_conv_desc* d, const float* dy,
     return conv2d_bwd_data_impl(d, dy, wT, addend, dx, stream, &bn);
 }
 
+extern "C" int vspw_conv2d_bwd_data_aff(const vspw_conv_desc* d, const float* g, const float* y, const float* coef,
+                                        const float* wT, const float* addend, const float* relu_src, const float* bn_y,
+                                        const float* bn_mean, const float* bn_invstd, float* dx, float* stat_part,
+                                        void* stream) {
+    if (!g || !y || !coef) return VSPW_EINVAL;
+    AffA aff = {y, coef};
+    if (relu_src || bn_y || bn_mean || bn_invstd || stat_part) {
+        if (!relu_src || !bn_y || !bn_mean || !bn_invstd || !stat_part) return VSPW_EINVAL;
+        if (vspw_conv2d_bwd_data_bn_partials(d) == 0) return VSPW_EINVAL;
+        BnFront bn = {relu_src, bn_y, bn_mean, bn_invstd, stat_part};
+        return conv2d_bwd_data_impl(d, g, wT, addend, dx, stream, &bn, &aff);
+    }
+    return conv2d_bwd_data_impl(d, g, wT, addend, dx, stream, nullptr, &aff);
+}
+
 static bool fill_bwd_data_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr; p.addend = nullptr;
     p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
+    p.src2 = nullptr; p.coef = nullptr;
     p.nb = d->n; p.h = d->oh; p.w = d->ow; p.c = d->k;   // gather over dY
     p.oh = d->h; p.ow = d->w;                              // rows are input pixels
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;
@@ -1551,11 +1643,19 @@ static bool fill_bwd_data_params(const vspw_conv_desc* d, IgemmNT& p) {
 }
 
 static int conv2d_bwd_data_impl(const vspw_conv_desc* d, const float* dy, const float* wT, const float* addend,
-                                float* dx, void* stream, const BnFront* bn) {
+                                float* dx, void* stream, const BnFront* bn, const AffA* aff) {
     if (!conv_geometry_ok(d) || !dy || !wT || !dx) return VSPW_EINVAL;
     IgemmNT p;
     if (!fill_bwd_data_params(d, p)) return VSPW_EINVAL;
     p.src = dy; p.wt = wT; p.dst = dx; p.addend = addend;
+    if (aff) {
+        bool v2;
+        nt_decide(p, v2);
+        const bool pw = p.kh * p.kw == 1 && p.stride == 1 && p.pad == 0 && p.padw == 0;
+        if (!v2 || !pw || !aff->y || !aff->coef) return VSPW_EINVAL;
+        p.src2 = aff->y;
+        p.coef = aff->coef;
+    }
     if (bn) {
         p.relu_src = bn->relu_src; p.bn_y = bn->bn_y; p.bn_mean = bn->bn_mean; p.bn_invstd = bn->bn_invstd;
         p.stat_part = bn->stat_part;
@@ -1595,8 +1695,23 @@ extern "C" size_t vspw_conv2d_bwd_weight_workspace(const vspw_conv_desc* d) {
     return (size_t)splits * d->k * d->kh * d->kw * d->c * sizeof(float);
 }
 
+static int conv2d_bwd_weight_impl(const vspw_conv_desc* d, const float* dy, const float* x, float* dw, void* ws,
+                                  size_t ws_bytes, void* stream, const AffA* aff);
+
 extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, const float* x, float* dw,
                                       void* ws, size_t ws_bytes, void* stream) {
+    return conv2d_bwd_weight_impl(d, dy, x, dw, ws, ws_bytes, stream, nullptr);
+}
+
+extern "C" int vspw_conv2d_bwd_weight_aff(const vspw_conv_desc* d, const float* g, const float* y, const float* coef,
+                                          const float* x, float* dw, void* ws, size_t ws_bytes, void* stream) {
+    if (!y || !coef) return VSPW_EINVAL;
+    AffA aff = {y, coef};
+    return conv2d_bwd_weight_impl(d, g, x, dw, ws, ws_bytes, stream, &aff);
+}
+
+static int conv2d_bwd_weight_impl(const vspw_conv_desc* d, const float* dy, const float* x, float* dw, void* ws,
+                                  size_t ws_bytes, void* stream, const AffA* aff) {
     if (!conv_geometry_ok(d) || !dy || !x || !dw) return VSPW_EINVAL;
     int splits, chunk;
     wgrad_plan(d, splits, chunk);
@@ -1616,6 +1731,8 @@ extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, 
     p.chunk = chunk;
     p.vec_a = (d->k % 4 == 0) ? 1 : 0;
     p.vec_b = (d->c % 4 == 0) ? 1 : 0;
+    p.dy2 = aff ? aff->y : nullptr;
+    p.coef = aff ? aff->coef : nullptr;
     const bool v2 = p.vec_a && p.vec_b && (long long)p.P * p.k < 0x7fffffffLL &&
                     (long long)d->n * d->h * d->w * d->c < 0x7fffffffLL;
     int tm, tn;
@@ -1623,7 +1740,16 @@ extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, 
     if (!v2) tm = tn = 128;
     const dim3 grid(vspw_cdiv(p.k, tm) * vspw_cdiv(p.ncols, tn), splits);
     hipStream_t st_ = vspw_stream(stream);
-    if (!v2) {
+    if (aff) {
+        // affine dY: pointwise, vector path, 128-row dY tiles and pixel chunks without a ragged last K-tile only
+        const bool point = d->stride == 1 && d->oh == d->h && d->ow == d->w && d->kh * d->kw == 1 && d->pad == 0 &&
+                           d->pad_w == 0;
+        if (!v2 || !point || tm != 128 || p.P % BK != 0) return VSPW_EINVAL;
+        if (tn == 128)
+            hipLaunchKernelGGL((igemm_tn_v2_kernel<5, TN_NBUF, 2, 2>), grid, dim3(256), 0, st_, p);
+        else
+            hipLaunchKernelGGL((igemm_tn_v2_kernel<5, 1, 2, 1>), grid, dim3(256), 0, st_, p);
+    } else if (!v2) {
         hipLaunchKernelGGL(igemm_tn_kernel, grid, dim3(256), 0, st_, p);
     } else {
         // gather mode (see igemm_tn_v2_kernel)

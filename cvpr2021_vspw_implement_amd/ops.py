@@ -227,13 +227,31 @@ def drop_weight_transpose_cache():
     _wt_cache.update(entries={}, order=[], table=None, table_n=0, tiles=0)
 
 
-def conv2d_backward_data(dy, w, d, addend=None, bn_front=None):
+def conv2d_backward_data(dy, w, d, addend=None, bn_front=None, aff=None):
     """dx = conv_backward_input(dy, w) [+ addend, folded into the GEMM epilogue].
     bn_front = (z, link): additionally apply the ReLU mask of the node that produced this conv's input z and leave the
-    two batch-norm-backward reductions of that node in link.partials (see BNLink); returns the masked gradient."""
+    two batch-norm-backward reductions of that node in link.partials (see BNLink); returns the masked gradient.
+    aff = (y, coef): `dy` is really g, the gradient w.r.t. the BatchNorm OUTPUT; the GEMM stages
+    coef[0]*g + coef[1]*y + coef[2] (BatchNorm's backward apply) as its operand (pointwise convs only)."""
     k, c, kh, kw = w.shape
     wT = _transposed_weight(w)
     dx = empty_nhwc(d.n, d.c, d.h, d.w, dy.device)
+    if aff is not None:
+        y_, coef = aff
+        if addend is not None:
+            addend = to_nhwc(addend)
+        zz = link = part = None
+        if bn_front is not None:
+            zz, link = bn_front
+            tiles = _C.query("vspw_conv2d_bwd_data_bn_partials", ctypes.byref(d))
+            part = torch.empty((tiles, 2, d.c), device=dy.device, dtype=torch.float32)
+        with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "dgrad")):
+            _C.call("vspw_conv2d_bwd_data_aff", ctypes.byref(d), _p(dy), _p(y_), _p(coef), _p(wT), _p(addend), _p(zz),
+                    _p(link.y) if link else None, _p(link.mean) if link else None,
+                    _p(link.invstd) if link else None, _p(dx), _p(part), _stream())
+        if link is not None:
+            link.partials, link.g = part, dx
+        return dx
     if addend is not None:
         addend = to_nhwc(addend)
         if tuple(addend.shape) != tuple(dx.shape):
@@ -278,30 +296,35 @@ def join_side_streams():
         _wgrad_side["dirty"] = False
 
 
-def _wgrad_launch(dy, x, d):
+def _wgrad_launch(dy, x, d, aff=None):
     dw = torch.empty((d.k, d.kh, d.kw, d.c), device=dy.device, dtype=torch.float32).permute(0, 3, 1, 2)
     nbytes = _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d))
     ws = _ws(nbytes, dy.device) if nbytes else None
     with _Timed("igemm_tn_kernel", _conv_flops(d), _conv_tag(d, "wgrad")):
-        _C.call("vspw_conv2d_bwd_weight", ctypes.byref(d), _p(dy), _p(x), _p(dw), _p(ws), nbytes, _stream())
+        if aff is None:
+            _C.call("vspw_conv2d_bwd_weight", ctypes.byref(d), _p(dy), _p(x), _p(dw), _p(ws), nbytes, _stream())
+        else:
+            _C.call("vspw_conv2d_bwd_weight_aff", ctypes.byref(d), _p(dy), _p(aff[0]), _p(aff[1]), _p(x), _p(dw), _p(ws),
+                    nbytes, _stream())
     return dw, ws
 
 
-def conv2d_backward_weight(dy, x, d):
+def conv2d_backward_weight(dy, x, d, aff=None):
+    """aff = (y, coef): see conv2d_backward_data."""
     if not _wgrad_side["enabled"] or _ktimer["on"]:
-        return _wgrad_launch(dy, x, d)[0]
+        return _wgrad_launch(dy, x, d, aff)[0]
     main = torch.cuda.current_stream()
     side = _wgrad_side["stream"]
     if side is None:
         side = _wgrad_side["stream"] = torch.cuda.Stream(device=dy.device)
     side.wait_stream(main)  # fork: dY (and X) are complete on the main stream
     with torch.cuda.stream(side):
-        dw, ws = _wgrad_launch(dy, x, d)
+        dw, ws = _wgrad_launch(dy, x, d, aff)
     # dY / X / the workspace were allocated on the main stream's pool: keep them alive until the join so that the
     # allocator cannot hand their memory to a later main-stream kernel while the side-stream GEMM still reads it
     # (dW itself must NOT be referenced here: with a second owner autograd's AccumulateGrad would clone it - a copy on
     # the main stream that races with the side-stream GEMM - instead of adopting the tensor as p.grad)
-    _wgrad_side["keep"].append((dy, x, ws))
+    _wgrad_side["keep"].append((dy, x, ws, aff))
     if not _wgrad_side["dirty"]:
         _wgrad_side["dirty"] = True
         try:  # join when this backward pass ends, so that p.grad is safe to read on the main stream afterwards
@@ -533,7 +556,8 @@ class BNLink(object):
         self.rows = self.c = 0
 
 
-_bn_fusion = {"enabled": os.environ.get("VSPW_NO_BN_FUSION", "0") != "1", "fused_nodes": 0}
+_bn_fusion = {"enabled": os.environ.get("VSPW_NO_BN_FUSION", "0") != "1", "fused_nodes": 0,
+              "affine": os.environ.get("VSPW_NO_BN_AFFINE", "0") != "1", "affine_nodes": 0}
 
 
 def set_bn_backward_fusion(enabled):
@@ -632,7 +656,8 @@ class ConvBNActFn(torch.autograd.Function):
         link = ctx.out_link
         fused = link is not None and link.partials is not None and link.g is not None and \
             link.g.data_ptr() == dz.data_ptr() and tuple(link.g.shape) == tuple(dz.shape)
-        dy = empty_nhwc(n, c, h, wd, dev)
+        dy = None
+        aff = None
         if fused:
             # the consumer's data gradient already masked dz with this node's ReLU and left the two reductions behind
             _bn_fusion["fused_nodes"] += 1
@@ -640,8 +665,21 @@ class ConvBNActFn(torch.autograd.Function):
             _C.call("vspw_bn_bwd_reduce_partials_f32", _p(part), part.shape[0], c, _p(sums), _p(dgamma), _p(dbeta), st)
             if ctx.training and ctx.world != 1:
                 _all_reduce_sums(sums)
-            _C.call("vspw_bn_bwd_apply", _p(dz), None, _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums),
-                    ctypes.c_double(ctx.count), None, rows, c, h * wd, 0, train, _p(dy), None, None, None, st)
+            pointwise = d.kh == 1 and d.kw == 1 and d.stride == 1 and d.pad == 0 and d.pad_w == 0
+            if (_bn_fusion["affine"] and pointwise and not ctx.has_cbias and d.c % 32 == 0 and c % 4 == 0 and c > 64
+                    and rows % 32 == 0):
+                # pointwise conv: BatchNorm's backward apply becomes an affine map staged by the two gradient GEMMs of
+                # this conv - dy (the gradient w.r.t. the conv output) is never written
+                coef = torch.empty((3, c), device=dev, dtype=torch.float32)
+                _C.call("vspw_bn_bwd_affine_coeffs", _p(sums), ctypes.c_double(ctx.count), _p(gamma), _p(mean),
+                        _p(invstd), _p(coef), c, train, st)
+                aff = (y, coef)
+                dy = dz
+                _bn_fusion["affine_nodes"] += 1
+            else:
+                dy = empty_nhwc(n, c, h, wd, dev)
+                _C.call("vspw_bn_bwd_apply", _p(dz), None, _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums),
+                        ctypes.c_double(ctx.count), None, rows, c, h * wd, 0, train, _p(dy), None, None, None, st)
             dres = dz if (ctx.has_res and ctx.needs_input_grad[7]) else None  # dres = g, which dz already is
         else:
             nbytes = _C.query("vspw_bn_bwd_workspace", rows, c)
@@ -652,6 +690,7 @@ class ConvBNActFn(torch.autograd.Function):
             if ctx.training and ctx.world != 1:
                 _all_reduce_sums(sums)
             dres = empty_nhwc(n, c, h, wd, dev) if (ctx.has_res and ctx.needs_input_grad[7]) else None
+            dy = empty_nhwc(n, c, h, wd, dev)
             _C.call("vspw_bn_bwd_apply", _p(dz), _p(z), _p(y), _p(mean), _p(invstd), _p(gamma), _p(sums),
                     ctypes.c_double(ctx.count), _p(mask), rows, c, h * wd, relu, train, _p(dy), _p(dres), None, None,
                     st)
@@ -664,9 +703,9 @@ class ConvBNActFn(torch.autograd.Function):
             front = None
             if ctx.in_link is not None and ctx.in_link.y is not None and _bn_fusion["enabled"]:
                 front = (x, ctx.in_link)
-            dx = conv2d_backward_data(dy, w, d, addend=dskip if ctx.skip_out else None, bn_front=front)
+            dx = conv2d_backward_data(dy, w, d, addend=dskip if ctx.skip_out else None, bn_front=front, aff=aff)
         if ctx.needs_input_grad[1]:
-            dw = conv2d_backward_weight(dy, x, d)
+            dw = conv2d_backward_weight(dy, x, d, aff=aff)
         if ctx.has_cbias and ctx.needs_input_grad[2]:
             dcb = colsum(rows, c, dy)
         return (dx, dw, dcb, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None,

@@ -81,6 +81,22 @@ int vspw_conv2d_bwd_data_bn(const vspw_conv_desc* d, const float* dy, const floa
 size_t vspw_conv2d_bwd_weight_workspace(const vspw_conv_desc* d);
 int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, const float* x, float* dw, void* ws,
                            size_t ws_bytes, void* stream);
+/* BatchNorm-backward "apply" folded into the operand load of a POINTWISE convolution's two gradient GEMMs
+ * (models/resnet.py:61,66 - conv1 / conv3 of a Bottleneck - followed by batchnorm.py:68-98): instead of materialising
+ * dy = a*(g - mean(g) - xhat*mean(g*xhat)) (one pass reading g and y, writing dy, which both GEMMs then re-read), the
+ * GEMMs stage  coef[0][k]*g + coef[1][k]*y + coef[2][k]  on the fly.  g: gradient w.r.t. the node's (masked) output,
+ * y: its pre-BN activations, coef [3][k] from vspw_bn_bwd_affine_coeffs (sums = the [2][k] fp64 reductions that
+ * vspw_bn_bwd_reduce_partials_f32 produces).  The data-gradient variant composes with the skip addend and with the
+ * fused BN-backward front end (relu_src .. stat_part: all NULL or all set, as vspw_conv2d_bwd_data_bn).  Restrictions
+ * (VSPW_EINVAL otherwise): 1x1, stride 1, no padding, Cin % 32 == 0 for the data gradient; Cout > 64 and
+ * n*oh*ow % 32 == 0 for the weight gradient. */
+int vspw_bn_bwd_affine_coeffs(const double* sums, double count, const float* gamma, const float* mean,
+                              const float* invstd, float* coef, int c, int training, void* stream);
+int vspw_conv2d_bwd_data_aff(const vspw_conv_desc* d, const float* g, const float* y, const float* coef, const float* wT,
+                             const float* addend, const float* relu_src, const float* bn_y, const float* bn_mean,
+                             const float* bn_invstd, float* dx, float* stat_part, void* stream);
+int vspw_conv2d_bwd_weight_aff(const vspw_conv_desc* d, const float* g, const float* y, const float* coef, const float* x,
+                               float* dw, void* ws, size_t ws_bytes, void* stream);
 /* [k][taps][c] -> [c][taps][k] */
 int vspw_weight_transpose(const float* w, float* wT, int k, int taps, int c, void* stream);
 /* The same transpose for many weight tensors in ONE launch.  `entries` is a DEVICE array sorted by tile0 (= the sum of

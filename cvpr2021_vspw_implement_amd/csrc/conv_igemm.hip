@@ -26,6 +26,14 @@
 #define BK 32
 #define LDA 36  // padded LDS row stride (floats): 16 consecutive rows hit 16 distinct 16-B slots
 
+#ifdef VSPW_NT_TIMING
+// DIAGNOSTIC build (-DVSPW_NT_TIMING): per-workgroup s_memtime stamps [start, after prologue, after K loop, end] + CU id
+__device__ unsigned long long vspw_nt_stamps[8192 * 5];
+#define NT_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 8192) vspw_nt_stamps[blockIdx.x * 5 + (i)] = __builtin_readcyclecounter()
+#else
+#define NT_STAMP(i)
+#endif
+
 struct IgemmNT {
     const float* src;   // gathered tensor [nb][h][w][c]
     const float* wt;    // [nout][kdim]
@@ -331,6 +339,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
     IgemmNT p) {
     static_assert(TAPS == 0 || (NBUF == 1 && MODE != 2), "tap-inner order: single LDS buffer, non-pointwise");
     static_assert(!AFF || (MODE == 2 && NBUF == 1), "affine A operand: pointwise, single LDS buffer");
+    NT_STAMP(0);
     constexpr int WGN = 4 / WGM;
     constexpr int TM = 32 * WM * WGM, TN = 32 * WN * WGN;
     constexpr int RA = TM / 32, RB = TN / 32;
@@ -506,6 +515,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     }
 
+    NT_STAMP(1);
     if constexpr (TAPS > 0) {
         // ---- channel-slab-outer / tap-inner K loop (see the template comment) ----
         unsigned a_toff[TAPS][RA];
@@ -619,6 +629,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
         __syncthreads();
     }
     }  // tap-outer order
+    NT_STAMP(2);
 
     float csum[WN], csq[WN];
     if (interior) {
@@ -729,7 +740,24 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
             }
         }
     }
+    __builtin_amdgcn_s_waitcnt(0);  // (only meaningful for the diagnostic stamp: stores drained)
+    NT_STAMP(3);
+#ifdef VSPW_NT_TIMING
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        vspw_nt_stamps[blockIdx.x * 5 + 4] = ((unsigned long long)xcc << 32) | id;
+    }
+#endif
 }
+
+#ifdef VSPW_NT_TIMING
+extern "C" int vspw_debug_nt_stamps(unsigned long long* host_out, int n) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(vspw_nt_stamps), sizeof(unsigned long long) * n);
+}
+#endif
 
 // Tile choice.  fp32 MFMA work is uniform per output element, so apart from a small per-tile efficiency difference
 // (bigger tiles amortise barriers and fragment loads better) the scheduling loss is the tail: with workgroups handed
@@ -838,6 +866,9 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
 // buffers, the smaller tiles one (two would cap residency at 2 workgroups/CU and lose)
 static int nt_decide(const IgemmNT& p, bool& v2) {
     int cfg = nt_pick_tile(p.m, p.nout);
+    // the fused BatchNorm-backward front end makes the epilogue a long memory phase (three extra operand streams): the
+    // 96-row tile (48 accumulators, one more resident workgroup to overlap it with) beats 128x128 there (-10 %)
+    if (p.relu_src != nullptr && cfg == 22) cfg = 31;
     // 32-bit byte offsets relative to the first image a tile touches / the tile's first weight row
     const long long img_elems = (long long)p.h * p.w * p.lds;
     const long long span = (128 / ((long long)p.oh * p.ow) + 2) * img_elems;
@@ -1594,6 +1625,7 @@ extern "C" size_t vspw_conv2d_bwd_data_bn_partials(const vspw_conv_desc* d) {
     if (!conv_geometry_ok(d)) return 0;
     IgemmNT p;
     if (!fill_bwd_data_params(d, p)) return 0;
+    p.relu_src = reinterpret_cast<const float*>(16);  // only tested against nullptr by the tile choice
     bool v2;
     const int rows = nt_tile_rows(nt_decide(p, v2));
     return v2 ? (size_t)((p.m + rows - 1) / rows) : 0;

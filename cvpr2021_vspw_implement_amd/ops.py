@@ -557,7 +557,10 @@ class BNLink(object):
 
 
 _bn_fusion = {"enabled": os.environ.get("VSPW_NO_BN_FUSION", "0") != "1", "fused_nodes": 0,
-              "affine": os.environ.get("VSPW_NO_BN_AFFINE", "0") != "1", "affine_nodes": 0}
+              "affine": os.environ.get("VSPW_NO_BN_AFFINE", "0") != "1", "affine_nodes": 0,
+              # narrow outputs (conv1 of a bottleneck: dy is 1/4 the size of its input gradient) gain nothing: the pass
+              # saved is as cheap as the second operand stream it costs (measured: 256 ch +-0, 1024 ch -70 us / block)
+              "affine_min_c": int(os.environ.get("VSPW_AFFINE_MINC", "512"))}
 
 
 def set_bn_backward_fusion(enabled):
@@ -666,8 +669,8 @@ class ConvBNActFn(torch.autograd.Function):
             if ctx.training and ctx.world != 1:
                 _all_reduce_sums(sums)
             pointwise = d.kh == 1 and d.kw == 1 and d.stride == 1 and d.pad == 0 and d.pad_w == 0
-            if (_bn_fusion["affine"] and pointwise and not ctx.has_cbias and d.c % 32 == 0 and c % 4 == 0 and c > 64
-                    and rows % 32 == 0):
+            if (_bn_fusion["affine"] and pointwise and not ctx.has_cbias and d.c % 32 == 0 and c % 4 == 0
+                    and c >= _bn_fusion["affine_min_c"] and rows % 32 == 0):
                 # pointwise conv: BatchNorm's backward apply becomes an affine map staged by the two gradient GEMMs of
                 # this conv - dy (the gradient w.r.t. the conv output) is never written
                 coef = torch.empty((3, c), device=dev, dtype=torch.float32)

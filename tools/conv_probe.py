@@ -27,6 +27,12 @@ SHAPES = [
     ("l2.conv1 1x1 512->128", 10, 60, 60, 512, 128, 1, 1, 0, 1),
     ("l1.conv2 3x3 64->64 120", 10, 120, 120, 64, 64, 3, 1, 1, 1),
     ("stem.conv3 3x3 64->128 240", 10, 240, 240, 64, 128, 3, 1, 1, 1),
+    ("xK 3x3 d2 128->256", 10, 60, 60, 128, 256, 3, 1, 2, 2),
+    ("xK 3x3 d2 512->256", 10, 60, 60, 512, 256, 3, 1, 2, 2),
+    ("xK 3x3 d2 1024->256", 10, 60, 60, 1024, 256, 3, 1, 2, 2),
+    ("xK 1x1 512->256", 10, 60, 60, 512, 256, 1, 1, 0, 1),
+    ("xK 1x1 2048->256", 10, 60, 60, 2048, 256, 1, 1, 0, 1),
+    ("xK 1x1 4096->256", 10, 60, 60, 4096, 256, 1, 1, 0, 1),
 ]
 
 

@@ -249,7 +249,19 @@ def main():
     graphed = None
     if mode == "graph":
         optim.adjust_learning_rate(opt, 0, max_iters, 0.002)
-        graphed = GraphedStep(lambda: step_body(imgs, labs), warmup=2)
+        ok = True
+        try:
+            graphed = GraphedStep(lambda: step_body(imgs, labs), warmup=2)
+        except Exception as e:  # noqa: BLE001 - e.g. a collective this RCCL build cannot record
+            sys.stderr.write("rank %d: hipGraph capture of the step failed (%r); falling back to eager launches\n"
+                             % (rank, e))
+            ok = False
+        if collectives:  # every rank must take the same path: replay only if the capture worked everywhere
+            flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            ok = bool(flag.item() > 0.5)
+        if not ok:
+            graphed = None
 
     def run_step(it, eager=False):
         if graphed is None or eager:

@@ -36,6 +36,10 @@ for k, r in norms.items():
     rows.append((abs(np.linalg.norm(g[k]) - r) / max(r, 1e-3 * scale), abs(np.linalg.norm(g32[k]) - r) / max(r, 1e-3 * scale), k))
 eh = np.array([r[0] for r in rows]); er = np.array([r[1] for r in rows])
 print("per-param norm err: hip max %.3e rms %.3e | oracle32 max %.3e rms %.3e" % (eh.max(), np.sqrt((eh**2).mean()), er.max(), np.sqrt((er**2).mean())))
+print("   percentiles 50/90/99: hip %s | oracle32 %s" % (np.percentile(eh, [50, 90, 99]).round(5), np.percentile(er, [50, 90, 99]).round(5)))
+num = sum((np.linalg.norm(g[k]) - r) ** 2 for k, r in norms.items()); den = sum(r ** 2 for r in norms.values())
+num32 = sum((np.linalg.norm(g32[k]) - r) ** 2 for k, r in norms.items())
+print("   aggregate norm-vector error: hip %.3e oracle32 %.3e" % ((num / den) ** 0.5, (num32 / den) ** 0.5))
 rows.sort(reverse=True)
 for r in rows[:10]: print("hip %.3e or32 %.3e %s" % r)
 for k in ("encoder.conv1.weight", "encoder.layer3.22.conv2.weight", "encoder.layer4.2.conv3.weight"):

@@ -65,6 +65,11 @@ struct IgemmNT {
     // node's pre-BN activations y; coef [3][kdim] from vspw_bn_bwd_affine_coeffs.
     const float* src2;
     const float* coef;
+    // Forward "apply" fused into the NEXT pointwise convolution (FAP): this conv's input z is the previous node's
+    // relu(scale*y + shift + residual), which has not been materialised: src = y, src2 = residual, coef = [2][kdim]
+    // (scale, shift); the A operand is evaluated while it is staged and - by the workgroups of the first column tile -
+    // also written to zout ([m][lds], the tensor every later reader of z uses).
+    float* zout;
 };
 
 __device__ __forceinline__ float nt_act(float v, int act) {
@@ -334,11 +339,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
 // the tap inside, one 32-channel slab of the window (1/8 of it) is reused by all nine taps while it sits in L2.  The
 // nine per-tap offsets of each staged row are computed ONCE (9*RA registers, hence 3 waves per SIMD), the K loop is
 // unrolled over the taps, and nothing is left of the per-tap refresh: its K loop has no VALU instruction at all.
-template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, bool AFF = false>
+template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, int AFF = 0>
 __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAPS == 0) ? 4 : ((NBUF == 1 && !(AFF && WM * WN > 3)) ? 3 : 2)) void igemm_nt_v2_kernel(
     IgemmNT p) {
     static_assert(TAPS == 0 || (NBUF == 1 && MODE != 2), "tap-inner order: single LDS buffer, non-pointwise");
-    static_assert(!AFF || (MODE == 2 && NBUF == 1), "affine A operand: pointwise, single LDS buffer");
+    static_assert(!AFF || (MODE == 2 && NBUF == 1), "transformed A operand: pointwise, single LDS buffer");
+    // AFF 1: A = coef0*src + coef1*src2 + coef2 (BatchNorm-backward apply); AFF 2: A = relu(coef0*src + coef1 + src2)
+    // (BatchNorm-forward apply + residual + ReLU of the producing node), also stored to zout
     NT_STAMP(0);
     constexpr int WGN = 4 / WGM;
     constexpr int TM = 32 * WM * WGM, TN = 32 * WN * WGN;
@@ -383,6 +390,9 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
         (int)(unsigned)(a_rem < (long long)NT_OOR ? a_rem : (long long)NT_OOR), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(AFF ? p.coef : p.wt), 0, 3 * p.kdim * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char*>(AFF == 2 ? p.zout + (size_t)img0 * p.h * p.w * p.lds : p.dst), 0,
+        (int)(unsigned)(a_rem < (long long)NT_OOR ? a_rem : (long long)NT_OOR), 0x00020000);
     // MODE 2 = pointwise at compile time (1x1, stride 1, no padding: source pixel == output pixel, every tap in the
     // image): no tap state, no in-image bits, no selects - the K loop is a plain GEMM loop
     constexpr bool PW = MODE == 2;
@@ -458,6 +468,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
     };
     f32x4 ra[RA], rb[RB];
     f32x4 ra2[AFF ? RA : 1], cf[3];
+    int kb_regs = 0;  // k base of the tile currently held in the staging registers (AFF 2: where its z goes)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     auto load_tile = [&]() {
         if (more) {
@@ -469,9 +480,10 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
                 for (int i = 0; i < RA; ++i)
                     ra2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a2, a_voff[i], cb * 4, 0));
 #pragma unroll
-                for (int e = 0; e < 3; ++e)
+                for (int e = 0; e < (AFF == 2 ? 2 : 3); ++e)
                     cf[e] = __builtin_bit_cast(
                         f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_c, (unsigned)(e * p.kdim + lcol) * 4u, kb * 4, 0));
+                kb_regs = kb;
             }
 #pragma unroll
             for (int i = 0; i < RB; ++i)
@@ -479,9 +491,21 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
         }
     };
     auto store_tile = [&](float* Ad, float* Bd) {
-        if (AFF) {  // the only vector-ALU work of this loop: 8 FMAs per staged float4
+        if (AFF == 1) {  // the only vector-ALU work of this loop: 8 FMAs per staged float4
 #pragma unroll
             for (int i = 0; i < RA; ++i) ra[i] = cf[0] * ra[i] + (cf[1] * ra2[i] + cf[2]);
+        }
+        if (AFF == 2) {  // same expression tree as bn_apply_kernel: (y*scale + shift) + residual, then ReLU
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                f32x4 v = ra[i] * cf[0] + cf[1];
+                v += ra2[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                ra[i] = v;
+                if (tile_n == 0)  // one column tile materialises z for the node's other readers (uniform branch)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_z, a_voff[i], kb_regs * 4, 0);
+            }
         }
 #pragma unroll
         for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(&Ad[(lrow + 32 * i) * LDA + lcol]) = ra[i];
@@ -794,25 +818,32 @@ static int nt_tile_rows(int cfg) { return (cfg == 22 || cfg == 21) ? 128 : (cfg 
 template <int MODE>
 static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
     if constexpr (MODE == 2) {
-        if (p.src2 != nullptr) {  // affine A operand (fused BatchNorm-backward apply)
-            if (cfg == 22) {
-                int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
-                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, 2, 1, 0, true>), dim3(tiles), dim3(256), 0, st, p);
-            } else if (cfg == 31) {
-                int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
-                hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, 2, 1, 0, true>), dim3(tiles), dim3(256), 0, st, p);
-            } else if (cfg == 12) {
-                int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
-                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, 2, 1, 0, true>), dim3(tiles), dim3(256), 0, st, p);
-            } else if (cfg == 21) {
-                int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);
-                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, 2, 1, 0, true>), dim3(tiles), dim3(256), 0, st, p);
-            } else {
-                int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
-                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, 2, 1, 0, true>), dim3(tiles), dim3(256), 0, st, p);
-            }
+#define NT_AFF_LAUNCH(A)                                                                                              \
+    if (cfg == 22) {                                                                                                  \
+        int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);                                                     \
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, 2, 1, 0, A>), dim3(tiles), dim3(256), 0, st, p);              \
+    } else if (cfg == 31) {                                                                                           \
+        int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);                                                      \
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, 2, 1, 0, A>), dim3(tiles), dim3(256), 0, st, p);              \
+    } else if (cfg == 12) {                                                                                           \
+        int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);                                                      \
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, 2, 1, 0, A>), dim3(tiles), dim3(256), 0, st, p);              \
+    } else if (cfg == 21) {                                                                                           \
+        int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);                                                      \
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, 2, 1, 0, A>), dim3(tiles), dim3(256), 0, st, p);              \
+    } else {                                                                                                          \
+        int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);                                                       \
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, 2, 1, 0, A>), dim3(tiles), dim3(256), 0, st, p);              \
+    }
+        if (p.src2 != nullptr && p.zout != nullptr) {  // fused forward apply of the producing node (A operand + z)
+            NT_AFF_LAUNCH(2)
             return;
         }
+        if (p.src2 != nullptr) {  // affine A operand (fused BatchNorm-backward apply)
+            NT_AFF_LAUNCH(1)
+            return;
+        }
+#undef NT_AFF_LAUNCH
     }
     if constexpr (MODE != 2) {
         static const int tap_inner = getenv("VSPW_TAP_INNER") ? atoi(getenv("VSPW_TAP_INNER")) : 1;
@@ -1544,7 +1575,7 @@ static int conv_geometry_ok(const vspw_conv_desc* d) {
 static bool fill_fwd_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr; p.addend = nullptr;
     p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
-    p.src2 = nullptr; p.coef = nullptr;
+    p.src2 = nullptr; p.coef = nullptr; p.zout = nullptr;
     p.nb = d->n; p.h = d->h; p.w = d->w; p.c = d->c;
     p.oh = d->oh; p.ow = d->ow;
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;
@@ -1575,6 +1606,29 @@ extern "C" int vspw_conv2d_fwd(const vspw_conv_desc* d, const float* x, const fl
     IgemmNT p;
     if (!fill_fwd_params(d, p)) return VSPW_EINVAL;
     p.src = x; p.wt = w; p.bias = bias; p.dst = y; p.stat_part = stat_part;
+    return launch_igemm_nt(p, vspw_stream(stream));
+}
+
+extern "C" size_t vspw_conv2d_fwd_apply_supported(const vspw_conv_desc* d) {
+    IgemmNT p;
+    if (!conv_geometry_ok(d) || !fill_fwd_params(d, p)) return 0;
+    bool v2;
+    nt_decide(p, v2);
+    return (v2 && p.kh * p.kw == 1 && p.stride == 1 && p.pad == 0 && p.padw == 0) ? 1 : 0;
+}
+
+extern "C" int vspw_conv2d_fwd_apply(const vspw_conv_desc* d, const float* y_in, const float* res_in,
+                                     const float* scale_shift, float* z_out, const float* w, const float* bias, float* y,
+                                     float* stat_part, void* stream) {
+    if (!conv_geometry_ok(d) || !y_in || !res_in || !scale_shift || !z_out || !w || !y) return VSPW_EINVAL;
+    IgemmNT p;
+    if (!fill_fwd_params(d, p)) return VSPW_EINVAL;
+    bool v2;
+    nt_decide(p, v2);
+    const bool pw = p.kh * p.kw == 1 && p.stride == 1 && p.pad == 0 && p.padw == 0;
+    if (!v2 || !pw) return VSPW_EINVAL;
+    p.src = y_in; p.src2 = res_in; p.coef = scale_shift; p.zout = z_out;
+    p.wt = w; p.bias = bias; p.dst = y; p.stat_part = stat_part;
     return launch_igemm_nt(p, vspw_stream(stream));
 }
 
@@ -1658,7 +1712,7 @@ extern "C" int vspw_conv2d_bwd_data_aff(const vspw_conv_desc* d, const float* g,
 static bool fill_bwd_data_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr; p.addend = nullptr;
     p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
-    p.src2 = nullptr; p.coef = nullptr;
+    p.src2 = nullptr; p.coef = nullptr; p.zout = nullptr;
     p.nb = d->n; p.h = d->oh; p.w = d->ow; p.c = d->k;   // gather over dY
     p.oh = d->h; p.ow = d->w;                              // rows are input pixels
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;

@@ -33,9 +33,15 @@ class _BlockSequential(nn.Sequential):
     block's input and the last block's output may have other readers (feature maps handed to the decoders)."""
 
     def forward(self, x):
-        for i, blk in enumerate(self):
-            x = blk(x, sole_consumer=True) if (i > 0 and isinstance(blk, Bottleneck)) else blk(x)
-        return x
+        blocks = list(self)
+        for i, blk in enumerate(blocks):
+            if isinstance(blk, Bottleneck):
+                # the next bottleneck's conv1 (pointwise) may evaluate this block's final BN + skip + ReLU itself
+                nxt = i + 1 < len(blocks) and isinstance(blocks[i + 1], Bottleneck)
+                x = blk(x, sole_consumer=i > 0, defer_output=nxt)
+            else:
+                x = blk(x)
+        return ops.materialize(x)
 
 
 class BasicBlock(nn.Module):
@@ -75,7 +81,7 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
-    def forward(self, x, sole_consumer=False):
+    def forward(self, x, sole_consumer=False, defer_output=False):
         """sole_consumer: nothing but this block reads x (true for every block but the first of a layer, see
         _BlockSequential) - lets conv1's data gradient carry the previous block's batch-norm backward reductions."""
         # the skip connection is taken from conv1's node (skip_out): in backward its gradient is added in conv1's
@@ -87,7 +93,7 @@ class Bottleneck(nn.Module):
             out = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
         out = vnn.conv_bn_act(out, self.conv2, self.bn2, relu=True, fuse_input=True)   # conv1's output: only read here
         return vnn.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=_residual_branch(self, skip),
-                               fuse_input=True)
+                               fuse_input=True, defer_apply=defer_output)
 
 
 class ResNet(nn.Module):

@@ -96,14 +96,15 @@ def dropout2d_mask(module, x_shape, device):
     return (torch.rand((n, c), device=device) < keep).float().div_(keep)
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None, dropout=None, skip_out=False, fuse_input=False):
+def conv_bn_act(x, conv, bn, relu=True, residual=None, dropout=None, skip_out=False, fuse_input=False,
+                defer_apply=False):
     """conv -> bn -> (+residual) -> relu -> dropout2d as one fused autograd node.  skip_out=True returns (out, x'):
     feed x' to the block's skip path and its gradient is added inside this conv's data-gradient GEMM.
     fuse_input=True asserts that this conv is the only consumer of x (see ops.BNLink)."""
     s, p, d = conv.geometry()
     mask = dropout2d_mask(dropout, (x.shape[0], conv.out_channels), x.device)
     return ops.conv_bn_act(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual,
-                           mask, s, p, d, bn.training, bn.momentum, bn.eps, relu, skip_out, fuse_input)
+                           mask, s, p, d, bn.training, bn.momentum, bn.eps, relu, skip_out, fuse_input, defer_apply)
 
 
 class AdaptiveAvgPool2d(nn.AdaptiveAvgPool2d):

@@ -122,8 +122,10 @@ def _ws(nbytes, device):
 
 
 # --------------------------------------------------------------------------------------------------- conv
-def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False):
-    """x NHWC-memory [N,C,H,W]; w [K,C,KH,KW] in channels_last memory ([K][KH][KW][C])."""
+def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None):
+    """x NHWC-memory [N,C,H,W]; w [K,C,KH,KW] in channels_last memory ([K][KH][KW][C]).
+    pending = (y_prev, scale_shift, residual): x has not been written yet - it is relu(scale*y_prev + shift +
+    residual) of the node that produced it; this (pointwise) GEMM evaluates it while staging and fills x."""
     _require_gpu(x, "conv2d")
     x = to_nhwc(x)
     if not is_nhwc(w):
@@ -138,7 +140,12 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False):
         tiles = _C.query("vspw_conv2d_stats_partials", ctypes.byref(d))
         part = torch.empty((tiles, 2, k), device=x.device, dtype=torch.float32)
     with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "fwd")):
-        _C.call("vspw_conv2d_fwd", ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y), _p(part), _stream())
+        if pending is not None:
+            py, pss, pres = pending
+            _C.call("vspw_conv2d_fwd_apply", ctypes.byref(d), _p(py), _p(pres), _p(pss), _p(x), _p(w), _p(bias), _p(y),
+                    _p(part), _stream())
+        else:
+            _C.call("vspw_conv2d_fwd", ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y), _p(part), _stream())
     return y, part, d
 
 
@@ -549,10 +556,10 @@ class BNLink(object):
     its epilogue (vspw_conv2d_bwd_data_bn), so the owner skips its reduction pass and the mask read.  Only valid when
     the consumer is the sole user of z - the model code asserts that by passing fuse_input=True."""
 
-    __slots__ = ("y", "mean", "invstd", "rows", "c", "partials", "g")
+    __slots__ = ("y", "mean", "invstd", "rows", "c", "partials", "g", "pending")
 
     def __init__(self):
-        self.y = self.mean = self.invstd = self.partials = self.g = None
+        self.y = self.mean = self.invstd = self.partials = self.g = self.pending = None
         self.rows = self.c = 0
 
 
@@ -561,6 +568,25 @@ _bn_fusion = {"enabled": os.environ.get("VSPW_NO_BN_FUSION", "0") != "1", "fused
               # narrow outputs (conv1 of a bottleneck: dy is 1/4 the size of its input gradient) gain nothing: the pass
               # saved is as cheap as the second operand stream it costs (measured: 256 ch +-0, 1024 ch -70 us / block)
               "affine_min_c": int(os.environ.get("VSPW_AFFINE_MINC", "512"))}
+
+
+# Forward apply deferred into the consumer (residual blocks): a conv+BN+residual+ReLU node whose output z has exactly
+# one next reader - a pointwise conv - leaves z unwritten and hands (y, scale/shift, residual) to that conv, whose GEMM
+# evaluates z while staging its A operand and writes it for everyone else (vspw_conv2d_fwd_apply).  Saves the separate
+# read-read-write pass of vspw_bn_apply plus the GEMM's own read of z.
+_fwd_apply = {"enabled": os.environ.get("VSPW_NO_FWD_APPLY", "0") != "1", "nodes": 0}
+
+
+def materialize(x):
+    """Write a deferred node output (see _fwd_apply) with the plain apply kernel; no-op for ordinary tensors."""
+    pend = getattr(x, "_vspw_pending", None)
+    if pend is not None:
+        py, pss, pres = pend
+        n, c, h, w = x.shape
+        _C.call("vspw_bn_apply", _p(py), _p(pss[0]), _p(pss[1]), _p(pres), None, _p(x), n * h * w, c, h * w, 1,
+                _stream())
+        x._vspw_pending = None
+    return x
 
 
 def set_bn_backward_fusion(enabled):
@@ -573,11 +599,11 @@ class ConvBNActFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, cbias, gamma, beta, running_mean, running_var, residual, mask, stride, pad, dil, training,
-                momentum, eps, relu, skip_out=False, in_link=None, out_link=None):
+                momentum, eps, relu, skip_out=False, in_link=None, out_link=None, pending=None, defer=False):
         _require_gpu(x, "conv_bn_act")
         x = to_nhwc(x)
         fuse_stats = training
-        y, part, d = conv2d_forward(x, w, cbias, stride, pad, dil, want_stats=fuse_stats)
+        y, part, d = conv2d_forward(x, w, cbias, stride, pad, dil, want_stats=fuse_stats, pending=pending)
         n, c, h, wd = y.shape
         rows = n * h * wd
         dev = x.device
@@ -615,8 +641,13 @@ class ConvBNActFn(torch.autograd.Function):
         if residual is not None:
             residual = to_nhwc(residual)
         z = empty_nhwc(n, c, h, wd, dev)
-        _C.call("vspw_bn_apply", _p(y), _p(scale), _p(shift), _p(residual), _p(mask), _p(z), rows, c, h * wd,
-                1 if relu else 0, st)
+        if defer and out_link is not None and residual is not None and mask is None and relu and c % 32 == 0:
+            # z is written by its one reader (see _fwd_apply); everything that touches it later (this node's backward,
+            # the reader's weight gradient, the next skip connection) runs after that reader on the same stream
+            out_link.pending = (y, coef[2:], residual)
+        else:
+            _C.call("vspw_bn_apply", _p(y), _p(scale), _p(shift), _p(residual), _p(mask), _p(z), rows, c, h * wd,
+                    1 if relu else 0, st)
         ctx.d = d
         ctx.training = training
         ctx.relu = relu
@@ -712,29 +743,50 @@ class ConvBNActFn(torch.autograd.Function):
         if ctx.has_cbias and ctx.needs_input_grad[2]:
             dcb = colsum(rows, c, dy)
         return (dx, dw, dcb, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None,
-                None, None)
+                None, None, None, None)
 
 
 def conv_bn_act(x, w, cbias, gamma, beta, running_mean, running_var, residual=None, mask=None, stride=1, pad=0,
-                dil=1, training=True, momentum=0.1, eps=1e-5, relu=True, skip_out=False, fuse_input=False):
+                dil=1, training=True, momentum=0.1, eps=1e-5, relu=True, skip_out=False, fuse_input=False,
+                defer_apply=False):
     """skip_out: also return the input as a second output (see ConvBNActFn.forward) - use THAT tensor for the skip
     connection of a residual block and its gradient is folded into this convolution's data-gradient epilogue.
     fuse_input: the caller guarantees this conv is the ONLY consumer of x; if x came out of a conv+BN+ReLU node, that
-    node's batch-norm backward reductions are then produced by this conv's data gradient (see BNLink)."""
+    node's batch-norm backward reductions are then produced by this conv's data gradient (see BNLink).
+    defer_apply: the caller guarantees that the NEXT thing done with the output is a conv_bn_act(fuse_input=True) call
+    on it (or ops.materialize): the output may come back unwritten, to be evaluated by that call (see _fwd_apply)."""
+    pending = getattr(x, "_vspw_pending", None)
+    if residual is not None:
+        materialize(residual)
     if not training and mask is None and not torch.is_grad_enabled() and _infer_fold["enabled"]:
         # inference: BatchNorm is an affine map per output channel - fold its scale into the weights, pass its shift as
         # the bias, add the residual and apply the ReLU in the GEMM epilogue: one launch, no pass over y
         _require_gpu(x, "conv_bn_act")
-        x = to_nhwc(x)
+        x = to_nhwc(materialize(x))
         z = _conv_bn_folded(x, w, cbias, gamma, beta, running_mean, running_var, residual, stride, pad, dil, eps, relu)
         return (z, x) if skip_out else z
     grad = torch.is_grad_enabled() and _bn_fusion["enabled"]
+    if pending is not None:
+        ok = fuse_input and is_nhwc(x) and w.shape[2] == 1 and w.shape[3] == 1 and stride == 1 and pad == 0
+        if ok:
+            ok = _C.query("vspw_conv2d_fwd_apply_supported",
+                          ctypes.byref(_conv_desc(x, w.shape[0], 1, 1, stride, pad, dil))) == 1
+        if not ok:
+            materialize(x)
+            pending = None
     in_link = getattr(x, "_vspw_link", None) if (fuse_input and grad and x.requires_grad) else None
     out_link = BNLink() if (grad and training and relu and mask is None) else None
+    defer = bool(defer_apply and _fwd_apply["enabled"] and out_link is not None)
     out = ConvBNActFn.apply(x, w, cbias, gamma, beta, running_mean, running_var, residual, mask, stride, pad, dil,
-                            training, momentum, eps, relu, skip_out, in_link, out_link)
+                            training, momentum, eps, relu, skip_out, in_link, out_link, pending, defer)
+    if pending is not None:
+        x._vspw_pending = None  # written by the GEMM just launched
+        _fwd_apply["nodes"] += 1
     if out_link is not None and out_link.y is not None:
-        (out[0] if skip_out else out)._vspw_link = out_link
+        z = out[0] if skip_out else out
+        z._vspw_link = out_link
+        if out_link.pending is not None:
+            z._vspw_pending, out_link.pending = out_link.pending, None
     return out
 
 

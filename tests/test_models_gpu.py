@@ -461,3 +461,40 @@ def test_bn_backward_affine_operand_matches_materialised_dy(dev):
     for k in g0:
         den = np.abs(g0[k]).max() + 1e-12
         assert np.abs(g1[k] - g0[k]).max() <= 2e-4 * den, (k, np.abs(g1[k] - g0[k]).max() / den)
+
+
+def test_deferred_forward_apply_is_bit_identical(dev):
+    """A bottleneck's final BatchNorm apply + skip + ReLU (reference models/resnet.py:83-90) evaluated inside the next
+    block's conv1 GEMM (vspw_conv2d_fwd_apply) against the separate apply pass: the same bits everywhere - loss, every
+    gradient, the running statistics - and the fused path is really taken (once per non-final bottleneck)."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    tag = "r50_clip_psp"
+    inp = clip_inputs(tag, train_shape=(2, 3, 57, 57))
+    results = []
+    for fused in (True, False):
+        ops._fwd_apply["enabled"] = fused
+        ops._fwd_apply["nodes"] = 0
+        try:
+            mod = build("clip_psp", "resnet50dilated")
+            load_det(mod)
+            zero_dropout(mod)
+            mod.to(dev).train()
+            imgs = [_t(a, dev) for a in inp["train_imgs"]]
+            labs = [_t(a, dev) for a in inp["train_labs"]]
+            loss, _ = mod({"img_data": imgs[-1], "seg_label": labs[-1], "clipimgs_data": imgs[:-1],
+                           "cliplabels_data": labs[:-1]})
+            loss.backward()
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            stats = {k: v.detach().cpu().numpy() for k, v in mod.state_dict().items() if "running_" in k}
+            results.append((loss.item(), _grads(mod), stats, ops._fwd_apply["nodes"]))
+        finally:
+            ops._fwd_apply["enabled"] = True
+    (l1, g1, s1, n1), (l0, g0, s0, n0) = results
+    assert n1 == (3 - 1) + (4 - 1) + (6 - 1) + (3 - 1) and n0 == 0, (n1, n0)
+    assert l1 == l0
+    for k in g0:
+        assert np.array_equal(g1[k], g0[k]), k
+    for k in s0:
+        assert np.array_equal(s1[k], s0[k]), k

@@ -10,7 +10,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "vspw_hip.h")
-LIB_PATH = os.path.join(_HERE, "lib", "libvspw_hip.so")
+# VSPW_HIP_LIB: a diagnostic build of the same library (tools/diag/*: -DVSPW_NT_TIMING / -DVSPW_NT_DBG variants)
+LIB_PATH = os.environ.get("VSPW_HIP_LIB") or os.path.join(_HERE, "lib", "libvspw_hip.so")
 
 
 class ConvDesc(ctypes.Structure):

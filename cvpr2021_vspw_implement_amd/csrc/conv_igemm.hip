@@ -20,6 +20,7 @@
 // so LDS and global bandwidth are far from binding; the kernel is MFMA-issue bound.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 #define BM 128
 #define BN 128
@@ -70,6 +71,9 @@ struct IgemmNT {
     // (scale, shift); the A operand is evaluated while it is staged and - by the workgroups of the first column tile -
     // also written to zout ([m][lds], the tensor every later reader of z uses).
     float* zout;
+#ifdef VSPW_NT_DBG
+    int dbg;  // diagnostic builds only (tools/diag/nt_exposed.py): 1 = no epilogue memory traffic, 2 = no K loop
+#endif
 };
 
 __device__ __forceinline__ float nt_act(float v, int act) {
@@ -339,6 +343,17 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
 // the tap inside, one 32-channel slab of the window (1/8 of it) is reused by all nine taps while it sits in L2.  The
 // nine per-tap offsets of each staged row are computed ONCE (9*RA registers, hence 3 waves per SIMD), the K loop is
 // unrolled over the taps, and nothing is left of the per-tap refresh: its K loop has no VALU instruction at all.
+// Wave priority outside the K loop.  fp32 MFMA occupies the SIMD's vector lanes for 64 cycles an instruction, so a
+// wave in its prologue (address arithmetic) or epilogue (a few hundred dependent VALU / LDS / memory instructions)
+// that shares a SIMD with two waves issuing MFMAs back to back gets one instruction in per MFMA: measured 8-16 k cycles
+// of prologue and 20-60 k cycles of epilogue per tile, during which the workgroup's registers and LDS are held without
+// feeding the matrix pipe.  Raised priority lets those phases issue back to back (the MFMA pipe loses the same issue
+// slots either way) and frees the slot for the next tile sooner.
+#ifndef NT_PRIO_EDGE
+#define NT_PRIO_EDGE 2
+#endif
+#define NT_PRIO(x) __builtin_amdgcn_s_setprio(x)
+
 template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, int AFF = 0>
 __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAPS == 0) ? 4 : ((NBUF == 1 && !(AFF && WM * WN > 3)) ? 3 : 2)) void igemm_nt_v2_kernel(
     IgemmNT p) {
@@ -347,11 +362,15 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
     // AFF 1: A = coef0*src + coef1*src2 + coef2 (BatchNorm-backward apply); AFF 2: A = relu(coef0*src + coef1 + src2)
     // (BatchNorm-forward apply + residual + ReLU of the producing node), also stored to zout
     NT_STAMP(0);
+    NT_PRIO(NT_PRIO_EDGE);
     constexpr int WGN = 4 / WGM;
     constexpr int TM = 32 * WM * WGM, TN = 32 * WN * WGN;
     constexpr int RA = TM / 32, RB = TN / 32;
-    __shared__ __attribute__((aligned(16))) float As[NBUF][TM * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[NBUF][TN * LDA];
+    // one LDS block: the operand tiles of the K loop, reused by the epilogue as per-wave transposition scratch
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * (TM + TN) * LDA];
+    static_assert(NBUF * (TM + TN) * LDA >= 4 * 32 * LDA, "epilogue scratch: 32 x LDA floats per wave");
+    float (*As)[TM * LDA] = reinterpret_cast<float (*)[TM * LDA]>(smem);
+    float (*Bs)[TN * LDA] = reinterpret_cast<float (*)[TN * LDA]>(smem + NBUF * TM * LDA);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -514,38 +533,30 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
     };
 
     f32x16 acc[WM][WN];
-    // interior tile (uniform): unguarded epilogue.  With a skip-connection addend the accumulators START from it
-    // (C = addend, then C += A*B): its loads are issued here, in the shadow of the first operand tiles, instead of in
-    // the epilogue where nothing hides their latency.
-    const bool interior = (m0 + TM <= p.m) & (n0 + TN <= p.nout) & (p.act <= 1);  // none or ReLU
-    const unsigned lane_off = (unsigned)((wm * 32 * WM + 4 * lh) * p.ldd + wn * 32 * WN + l31) * 4u;
-    if (p.addend != nullptr && interior) {
-        const char* abase = reinterpret_cast<const char*>(p.addend + (size_t)m0 * p.ldd + n0);
+    // interior tile (uniform): unguarded, 16-byte-per-lane epilogue (below)
+    const bool interior = (m0 + TM <= p.m) & (n0 + TN <= p.nout) & (p.act <= 1) & ((p.ldd & 3) == 0) &
+                          (WM * WN < 4 || p.relu_src == nullptr) &
+                          ((((size_t)p.dst | (size_t)p.addend | (size_t)p.relu_src | (size_t)p.bn_y | (size_t)p.bias |
+                             (size_t)p.bn_mean | (size_t)p.bn_invstd) & 15) == 0);
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const size_t uoff = ((size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldd + j * 32) * 4;
-                    acc[i][j][r] = *reinterpret_cast<const float*>(abase + uoff + lane_off);
-                }
-    } else {
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-            for (int j = 0; j < WN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     NT_STAMP(1);
+    NT_PRIO(0);
     if constexpr (TAPS > 0) {
         // ---- channel-slab-outer / tap-inner K loop (see the template comment) ----
         unsigned a_toff[TAPS][RA];
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) tap_offsets(t / 3, t % 3, a_toff[t]);
+#ifdef VSPW_NT_DBG
+        const int nslab = (p.dbg & 2) ? 0 : p.c / BK;
+#else
         const int nslab = p.c / BK;
+#endif
         auto load_kt = [&](int t, int cs) {  // t is a compile-time constant at every call site
 #pragma unroll
             for (int i = 0; i < RA; ++i)
@@ -590,7 +601,11 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
             }
         }
     } else {
+#ifdef VSPW_NT_DBG
+    const int nk = (p.dbg & 2) ? 0 : p.kdim / BK;
+#else
     const int nk = p.kdim / BK;
+#endif
     // prologue: tile 0 -> LDS[0]; tile 1 -> registers
     load_tile();
     if (NBUF == 2) {
@@ -654,58 +669,120 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
     }
     }  // tap-outer order
     NT_STAMP(2);
+    NT_PRIO(NT_PRIO_EDGE);
+#ifdef VSPW_NT_DBG
+    if (p.dbg & 1) {  // no epilogue traffic: keep the accumulators alive through a never-true store
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 123.456f) p.dst[tid] = t;
+        return;
+    }
+#endif
 
     float csum[WN], csq[WN];
+    f32x4 cs4[WN], cq4[WN];
     if (interior) {
-        // unguarded stores at `uniform base + constant per-lane byte offset` (any addend is already in acc)
-        char* dbase = reinterpret_cast<char*>(p.dst + (size_t)m0 * p.ldd + n0);
+        // The accumulator layout (lane = column, registers = rows) would make every global access of the epilogue a
+        // 4-byte-per-lane instruction - 16 per 32x32 block and stream, and the vector-memory pipe issues those no
+        // faster than 16-byte ones: with three workgroups per CU the stores (and the skip / BatchNorm-front loads) of
+        // one workgroup held up the operand loads of the other two (measured: 163 us with, 135 us without the store
+        // phase on the 1024->256 data gradient, and no overlap between the two).  So each 32x32 block goes through a
+        // wave-private LDS scratch (the operand tiles are dead: every wave is past the K loop's last barrier) and comes
+        // back with a lane owning 4 consecutive channels of rows (lane/8 + 8s): 4 x 16-byte accesses per block and
+        // stream, all element-wise work and the per-channel partial sums in that layout.
+        float* scr = smem + wave * (32 * LDA);
+        const int erow = lane >> 3, ec4 = (lane & 7) * 4;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        // the three switches are compile-time inside the body (straight-line code per block; as run-time tests the
+        // compiler re-branched on them for every 16-byte access)
+        auto epilogue = [&](auto ACT, auto ADD, auto BNF, auto STATS) {
+            constexpr bool act1 = decltype(ACT)::value, has_add = decltype(ADD)::value, bnf = decltype(BNF)::value;
+            constexpr bool stats = decltype(STATS)::value;  // per-channel partial sums wanted (p.stat_part)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            csum[j] = 0.f;
-            csq[j] = 0.f;
-            const float bv = (p.bias != nullptr) ? p.bias[n0 + wn * 32 * WN + j * 32 + l31] : 0.f;
-            if (p.relu_src != nullptr) {
-                // fused BN-backward front end: first every load (z and the pre-BN activations), then the stores - loads
-                // interleaved with stores would be serialised (dst may alias them as far as the compiler knows)
-                const char* zbase = reinterpret_cast<const char*>(p.relu_src + (size_t)m0 * p.ldd + n0);
-                const char* ybase = reinterpret_cast<const char*>(p.bn_y + (size_t)m0 * p.ldd + n0);
-                const int col = n0 + wn * 32 * WN + j * 32 + l31;
-                const float mu = p.bn_mean[col], is = p.bn_invstd[col];
-                float xh[WM][16];
+            for (int j = 0; j < WN; ++j) {
+                cs4[j] = zero4;
+                cq4[j] = zero4;
+                const int col = n0 + wn * 32 * WN + j * 32 + ec4;
+                const f32x4 bv4 = (p.bias != nullptr) ? *reinterpret_cast<const f32x4*>(p.bias + col) : zero4;
+                f32x4 mu4 = zero4, is4 = zero4;
+                if constexpr (bnf) {
+                    mu4 = *reinterpret_cast<const f32x4*>(p.bn_mean + col);
+                    is4 = *reinterpret_cast<const f32x4*>(p.bn_invstd + col);
+                }
 #pragma unroll
-                for (int i = 0; i < WM; ++i)
+                for (int i = 0; i < WM; ++i) {
+                    const size_t e0 = (size_t)(m0 + wm * 32 * WM + i * 32 + erow) * p.ldd + col;
+                    const size_t estep = (size_t)8 * p.ldd;
+                    // two half-blocks (rows erow + 0/8, then + 16/24): the half's loads first - they overlap the LDS
+                    // round trip / the previous half's arithmetic - then the arithmetic and the stores
+                    f32x4 ad[2][2], zz[2][2], yy[2][2];
+                    auto fetch = [&](int h) {  // h is a compile-time constant at every call site
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const size_t uoff = ((size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldd + j * 32) * 4;
-                        const float zv = *reinterpret_cast<const float*>(zbase + uoff + lane_off);
-                        xh[i][r] = *reinterpret_cast<const float*>(ybase + uoff + lane_off);
-                        if (!(zv > 0.f)) acc[i][j][r] = 0.f;
+                        for (int q = 0; q < 2; ++q) {
+                            const size_t e = e0 + (2 * h + q) * estep;
+                            if constexpr (has_add) ad[h][q] = *reinterpret_cast<const f32x4*>(p.addend + e);
+                            if constexpr (bnf) {
+                                zz[h][q] = *reinterpret_cast<const f32x4*>(p.relu_src + e);
+                                yy[h][q] = *reinterpret_cast<const f32x4*>(p.bn_y + e);
+                            }
+                        }
+                    };
+                    fetch(0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDA + l31] = acc[i][j][r];
+                    fetch(1);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int rq = 2 * h + q;
+                            f32x4 o = *reinterpret_cast<const f32x4*>(&scr[(rq * 8 + erow) * LDA + ec4]) + bv4;
+                            if constexpr (has_add) o += ad[h][q];  // act(conv + bias + addend)
+                            if constexpr (act1) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+                            }
+                            if constexpr (bnf) {  // fused BN-backward front end (see IgemmNT)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o[e] = (zz[h][q][e] > 0.f) ? o[e] : 0.f;
+                                cq4[j] += o * ((yy[h][q] - mu4) * is4);
+                            } else if constexpr (stats) {
+                                cq4[j] += o * o;
+                            }
+                            if constexpr (stats) cs4[j] += o;
+                            *reinterpret_cast<f32x4*>(p.dst + e0 + rq * estep) = o;
+                        }
                     }
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const size_t uoff = ((size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldd + j * 32) * 4;
-                        const float v = acc[i][j][r];
-                        *reinterpret_cast<float*>(dbase + uoff + lane_off) = v;
-                        csum[j] += v;
-                        csq[j] += v * ((xh[i][r] - mu) * is);
-                    }
-                continue;
-            }
-#pragma unroll
-            for (int i = 0; i < WM; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const size_t uoff = ((size_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * p.ldd + j * 32) * 4;  // uniform
-                    float v = acc[i][j][r] + bv;
-                    if (p.act == 1) v = fmaxf(v, 0.f);
-                    *reinterpret_cast<float*>(dbase + uoff + lane_off) = v;
-                    csum[j] += v;
-                    csq[j] += v * v;
+                    // one block at a time: without the fence the scheduler hoists every block's loads to the top of
+                    // the epilogue (3 streams x 16 registers x WM*WN blocks) and spills the accumulators
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        const bool has_add = p.addend != nullptr;
+        if (p.relu_src != nullptr) {
+            // (never launched on the 2x2-block-per-wave tile, see nt_decide: its 64 accumulators + three operand
+            // streams do not fit the register budget of 3 workgroups / CU)
+            if constexpr (WM * WN < 4) {
+                if (has_add) epilogue(F{}, T{}, T{}, T{}); else epilogue(F{}, F{}, T{}, T{});
+            }
+        } else if (p.act == 1) {  // (statistics are taken of pre-activation outputs: never together with ReLU)
+            if (has_add) epilogue(T{}, T{}, F{}, F{}); else epilogue(T{}, F{}, F{}, F{});
+        } else if (p.stat_part != nullptr) {
+            if (has_add) epilogue(F{}, T{}, F{}, T{}); else epilogue(F{}, F{}, F{}, T{});
+        } else {
+            if (has_add) epilogue(F{}, T{}, F{}, F{}); else epilogue(F{}, F{}, F{}, F{});
         }
+#if defined(VSPW_NT_TIMING) && VSPW_NT_TIMING == 2
+        NT_STAMP(1);  // experiment: slot 1 = every store of the tile issued (not drained)
+#endif
     } else {
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
@@ -739,14 +816,39 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
     if (p.stat_part != nullptr) {
         float* red = As[0];  // [2 stats][WGM][TN]  (TM*LDA >= 2*WGM*TN for every instantiated tile)
         __syncthreads();
+        if (interior) {
+            // a lane holds 4 channels' sums over the rows lane/8 + 8s of its wave's blocks: fold the 8 row groups
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            float s = csum[j] + __shfl_xor(csum[j], 32, 64);
-            float q = csq[j] + __shfl_xor(csq[j], 32, 64);
-            if (lh == 0) {
-                int c = wn * 32 * WN + j * 32 + l31;
-                red[(0 * WGM + wm) * TN + c] = s;
-                red[(1 * WGM + wm) * TN + c] = q;
+            for (int j = 0; j < WN; ++j) {
+                f32x4 s4 = cs4[j], q4 = cq4[j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = s4[e], b = q4[e];
+                    a += __shfl_xor(a, 8, 64);
+                    b += __shfl_xor(b, 8, 64);
+                    a += __shfl_xor(a, 16, 64);
+                    b += __shfl_xor(b, 16, 64);
+                    a += __shfl_xor(a, 32, 64);
+                    b += __shfl_xor(b, 32, 64);
+                    s4[e] = a;
+                    q4[e] = b;
+                }
+                if (lane < 8) {
+                    const int c = wn * 32 * WN + j * 32 + lane * 4;
+                    *reinterpret_cast<f32x4*>(&red[(0 * WGM + wm) * TN + c]) = s4;
+                    *reinterpret_cast<f32x4*>(&red[(1 * WGM + wm) * TN + c]) = q4;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                float s = csum[j] + __shfl_xor(csum[j], 32, 64);
+                float q = csq[j] + __shfl_xor(csq[j], 32, 64);
+                if (lh == 0) {
+                    int c = wn * 32 * WN + j * 32 + l31;
+                    red[(0 * WGM + wm) * TN + c] = s;
+                    red[(1 * WGM + wm) * TN + c] = q;
+                }
             }
         }
         __syncthreads();
@@ -764,9 +866,9 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
             }
         }
     }
-    __builtin_amdgcn_s_waitcnt(0);  // (only meaningful for the diagnostic stamp: stores drained)
-    NT_STAMP(3);
 #ifdef VSPW_NT_TIMING
+    __builtin_amdgcn_s_waitcnt(0);  // the diagnostic stamp counts the stores as drained; production waves just end
+    NT_STAMP(3);
     if (threadIdx.x == 0 && blockIdx.x < 8192) {
         unsigned id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
@@ -1576,6 +1678,9 @@ static bool fill_fwd_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr; p.addend = nullptr;
     p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
     p.src2 = nullptr; p.coef = nullptr; p.zout = nullptr;
+#ifdef VSPW_NT_DBG
+    p.dbg = getenv("VSPW_NT_DBG") ? atoi(getenv("VSPW_NT_DBG")) : 0;
+#endif
     p.nb = d->n; p.h = d->h; p.w = d->w; p.c = d->c;
     p.oh = d->oh; p.ow = d->ow;
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;
@@ -1713,6 +1818,9 @@ static bool fill_bwd_data_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr; p.addend = nullptr;
     p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
     p.src2 = nullptr; p.coef = nullptr; p.zout = nullptr;
+#ifdef VSPW_NT_DBG
+    p.dbg = getenv("VSPW_NT_DBG") ? atoi(getenv("VSPW_NT_DBG")) : 0;
+#endif
     p.nb = d->n; p.h = d->oh; p.w = d->ow; p.c = d->k;   // gather over dY
     p.oh = d->h; p.ow = d->w;                              // rows are input pixels
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;

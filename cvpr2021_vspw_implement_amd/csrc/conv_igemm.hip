@@ -1213,6 +1213,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(IgemmTN p) {
 // WM = 1 / WN = 1 so that no half of the MFMA tile is spent on padding.
 template <int G, int NBUF, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
+    NT_PRIO(NT_PRIO_EDGE);  // prologue / epilogue at raised priority (see NT_PRIO)
     constexpr bool LIN = G >= 2;
     constexpr bool WIDE = G >= 1;
     constexpr bool UNI = G == 4;  // linear + tap uniform per workgroup + rows uniform per half-wave: scalar validity
@@ -1465,6 +1466,7 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
             __syncthreads();
         }
     }
+    NT_PRIO(0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = (NBUF == 2) ? (kt & 1) : 0;
         if (NBUF == 1) {
@@ -1518,8 +1520,28 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
         __syncthreads();
     }
 
+    NT_PRIO(NT_PRIO_EDGE);
     float* out = p.part + (size_t)split * p.k * p.ncols;
     // (row / column of accumulator element r of block (i, j) under the interleaved fragment mapping above)
+    if (WN == 2 && (p.ncols & 1) == 0) {
+        // blocks j = 0, 1 of a lane are columns 2*l31 and 2*l31 + 1: one 8-byte store per (i, r) - half the store
+        // instructions of the element-wise form, and every one fills whole 32-byte sectors
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const int col = n0 + wn * 64 + 2 * l31;
+        if (col < p.ncols) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int row = m0 + wm * 32 * WM + (WM == 2 ? 2 * rr + i : rr);
+                    const f32x2 v = {acc[i][0][r], acc[i][WN - 1][r]};
+                    if (row < p.k) *reinterpret_cast<f32x2*>(&out[(size_t)row * p.ncols + col]) = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
         const int col = n0 + wn * 32 * WN + (WN == 2 ? 2 * l31 + j : l31);
@@ -1864,21 +1886,55 @@ static void wgrad_tile(const vspw_conv_desc* d, int& tm, int& tn) {
     tn = (vec && d->kh * d->kw * d->c <= 64) ? 64 : BN;
 }
 
+// Split-K plan of the weight gradient: how many pixel chunks (each one workgroup per output tile, partial slabs summed
+// by splitk_reduce_kernel in split order).  Workgroups are equal-sized, so the launch takes ceil(N / 256) "rounds" of
+// one workgroup per CU where N / 256 would do: the old rule (N ~ 768, whatever the tile count) left 864 workgroups for
+// the 1024->512 3x3 (3.4 rounds of work in 4: 114 TFLOP/s where the forward GEMM of the same shape reaches 141) and
+// 770 for the stem (3.008 in 4).  Cost model per candidate s (relative to the perfectly divisible GEMM):
+//     rounds(N) / (N / 256)            quantisation, N = tiles * splits
+//   x 1 / occupancy(N / 256)           1 / 2 / >= 3 resident workgroups per CU hide barrier and load latency differently
+//   x (1 + 6 / k_tiles)                per-workgroup prologue + epilogue, about six K-tiles' worth
+//   + 100 * s / P                      partial slabs written and re-read (2 x 4 bytes per output element and split
+//                                      against 2 * P flops per output element at ~125 TFLOP/s and ~4 TB/s)
 static void wgrad_plan(const vspw_conv_desc* d, int& splits, int& chunk) {
-    long long P = (long long)d->n * d->oh * d->ow;
-    int ncols = d->kh * d->kw * d->c;
+    const long long P = (long long)d->n * d->oh * d->ow;
+    const int ncols = d->kh * d->kw * d->c;
     int tm, tn;
     wgrad_tile(d, tm, tn);
-    long long tiles = (long long)vspw_cdiv(d->k, tm) * vspw_cdiv(ncols, tn);
-    long long want = (768 + tiles / 2) / tiles;  // 3 workgroups per CU, all resident at once (single LDS buffer)
+    const long long tiles = (long long)vspw_cdiv(d->k, tm) * vspw_cdiv(ncols, tn);
     long long max_splits = (P + 255) / 256;
-    if (want > max_splits) want = max_splits;
-    if (want < 1) want = 1;
-    if (want > 512) want = 512;
-    long long ch = (P + want - 1) / want;
-    ch = ((ch + BK - 1) / BK) * BK;
-    splits = (int)((P + ch - 1) / ch);
-    chunk = (int)ch;
+    if (max_splits > 512) max_splits = 512;
+    if (max_splits < 1) max_splits = 1;
+    static const int forced = getenv("VSPW_WGRAD_SPLITS") ? atoi(getenv("VSPW_WGRAD_SPLITS")) : 0;  // diagnostic sweep
+    if (forced > 0) {
+        long long ch = (P + forced - 1) / forced;
+        ch = ((ch + BK - 1) / BK) * BK;
+        splits = (int)((P + ch - 1) / ch);
+        chunk = (int)ch;
+        return;
+    }
+    double best = 1e30;
+    long long best_ch = ((P + BK - 1) / BK) * BK;
+    int best_s = 1;
+    for (long long want = 1; want <= max_splits; ++want) {
+        long long ch = (P + want - 1) / want;
+        ch = ((ch + BK - 1) / BK) * BK;
+        const long long sp = (P + ch - 1) / ch;
+        if (sp != want && want != 1) continue;  // this chunk size was already seen under a smaller `want`
+        const double n = (double)(tiles * sp);
+        const double per_cu = n / 256.0;
+        const double rounds = (double)((tiles * sp + 255) / 256);
+        const double occ = per_cu >= 3.0 ? 1.0 : (per_cu >= 2.0 ? 0.93 : 0.80);
+        const double kt = (double)(ch / BK);
+        const double cost = rounds / per_cu / occ * (1.0 + 6.0 / kt) + 100.0 * (double)sp / (double)P;
+        if (cost < best) {
+            best = cost;
+            best_ch = ch;
+            best_s = (int)sp;
+        }
+    }
+    splits = best_s;
+    chunk = (int)best_ch;
 }
 
 extern "C" size_t vspw_conv2d_bwd_weight_workspace(const vspw_conv_desc* d) {

@@ -31,8 +31,12 @@
 // DIAGNOSTIC build (-DVSPW_NT_TIMING): per-workgroup s_memtime stamps [start, after prologue, after K loop, end] + CU id
 __device__ unsigned long long vspw_nt_stamps[8192 * 5];
 #define NT_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 8192) vspw_nt_stamps[blockIdx.x * 5 + (i)] = __builtin_readcyclecounter()
+#define TN_STAMP(i)                                                                       \
+    if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 8192)                   \
+    vspw_nt_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 5 + (i)] = __builtin_readcyclecounter()
 #else
 #define NT_STAMP(i)
+#define TN_STAMP(i)
 #endif
 
 struct IgemmNT {
@@ -1213,6 +1217,7 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(IgemmTN p) {
 // WM = 1 / WN = 1 so that no half of the MFMA tile is spent on padding.
 template <int G, int NBUF, int WM, int WN>
 __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
+    TN_STAMP(0);
     NT_PRIO(NT_PRIO_EDGE);  // prologue / epilogue at raised priority (see NT_PRIO)
     constexpr bool LIN = G >= 2;
     constexpr bool WIDE = G >= 1;
@@ -1466,6 +1471,7 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
             __syncthreads();
         }
     }
+    TN_STAMP(1);
     NT_PRIO(0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = (NBUF == 2) ? (kt & 1) : 0;
@@ -1520,6 +1526,7 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
         __syncthreads();
     }
 
+    TN_STAMP(2);
     NT_PRIO(NT_PRIO_EDGE);
     float* out = p.part + (size_t)split * p.k * p.ncols;
     // (row / column of accumulator element r of block (i, j) under the interleaved fragment mapping above)
@@ -1540,6 +1547,16 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
                 }
             }
         }
+#ifdef VSPW_NT_TIMING
+        __builtin_amdgcn_s_waitcnt(0);
+        TN_STAMP(3);
+        if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 8192) {
+            unsigned id, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            vspw_nt_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 5 + 4] = ((unsigned long long)xcc << 32) | id;
+        }
+#endif
         return;
     }
 #pragma unroll

@@ -89,6 +89,49 @@ def test_conv_bn_act_skip_gradient_is_folded_into_dgrad(dev, n, c, h, w, k):
     _close(wd.grad, wr.grad, 3e-4, "wgrad")
 
 
+@pytest.mark.parametrize("n,cm,c,h,w,k,fused", [(2, 64, 256, 16, 24, 64, True),    # interior tiles, two K-tiles
+                                                 (3, 32, 1024, 20, 20, 256, True),  # layer-3 shape: 96-row tiles
+                                                 (1, 32, 64, 9, 13, 32, True),      # ragged rows: clamped A rows
+                                                 (2, 16, 48, 10, 10, 32, False)])   # C % 32 != 0: plain apply pass
+def test_block_output_evaluated_by_the_next_conv1(dev, n, cm, c, h, w, k, fused):
+    """A residual block's relu(bn3(conv3(u)) + skip) left to the next block's conv1 (models/resnet.py:83-90 then :75,
+    ops._fwd_apply / vspw_conv2d_fwd_apply): the block output, conv1's output and every gradient against autograd on
+    the plain composition; the fused kernel is taken exactly when the geometry allows it."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(31 + c)
+    u = torch.randn(n, cm, h, w, generator=g)
+    skip = torch.randn(n, c, h, w, generator=g)
+    w3 = torch.randn(c, cm, 1, 1, generator=g) * (2.0 / cm) ** 0.5
+    w1 = torch.randn(k, c, 1, 1, generator=g) * (2.0 / c) ** 0.5
+    g3, b3 = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    g1, b1 = torch.rand(k, generator=g) + 0.5, torch.randn(k, generator=g) * 0.1
+    go = torch.randn(n, k, h, w, generator=g)
+    gz = torch.randn(n, c, h, w, generator=g)  # the block output's second reader (the next skip connection)
+    ref = [t.clone().requires_grad_(True) for t in (u, skip, w3, w1)]
+    zr = F.relu(F.batch_norm(F.conv2d(ref[0], ref[2]), None, None, g3, b3, True, 0.1, 1e-5) + ref[1])
+    orr = F.relu(F.batch_norm(F.conv2d(zr, ref[3]), None, None, g1, b1, True, 0.1, 1e-5))
+    torch.autograd.backward([orr, zr], [go, gz])
+    dv = [u.to(dev).requires_grad_(True), skip.to(dev).requires_grad_(True),
+          w3.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True),
+          w1.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)]
+    stats = lambda ch: (torch.zeros(ch, device=dev), torch.ones(ch, device=dev))
+    before = ops._fwd_apply["nodes"]
+    zd = ops.conv_bn_act(dv[0], dv[2], None, g3.to(dev), b3.to(dev), *stats(c), residual=dv[1], training=True,
+                         relu=True, defer_apply=True)
+    assert (getattr(zd, "_vspw_pending", None) is not None) == (c % 32 == 0)
+    od, zskip = ops.conv_bn_act(zd, dv[3], None, g1.to(dev), b1.to(dev), *stats(k), training=True, relu=True,
+                                skip_out=True, fuse_input=True)
+    assert getattr(zd, "_vspw_pending", None) is None
+    assert ops._fwd_apply["nodes"] - before == (1 if fused else 0)
+    torch.autograd.backward([od, zskip], [go.to(dev), gz.to(dev)])
+    ops.join_side_streams()
+    _close(zd, zr, 1e-4, "block output")
+    _close(od, orr, 2e-4, "conv1 output")
+    for got, want, what in zip(dv, ref, ("d u", "d skip", "d w3", "d w1")):
+        _close(got.grad, want.grad, 5e-4, what)
+
+
 @pytest.mark.parametrize("shape,relu,res,train", [
     ((4, 64, 9, 11), True, False, True),
     ((2, 256, 7, 5), True, True, True),

@@ -63,3 +63,38 @@ def run(name, n, h, w, c, k, ks, pad, dil, mode):
 run("1x1 c1024 k256", 10, 60, 60, 1024, 256, 1, 0, 1, "dgrad")
 run("1x1 c1024 k256", 10, 60, 60, 1024, 256, 1, 0, 1, "dgrad+add")
 run("1x1 c256 k1024", 10, 60, 60, 256, 1024, 1, 0, 1, "fwd")
+
+
+def run_tn(name, n, hw, c, k, ks, pad, dil):
+    x = ops.empty_nhwc(n, c, hw, hw, dev).normal_()
+    wt = (torch.randn(k, ks, ks, c, device=dev) * 0.05).permute(0, 3, 1, 2)
+    y, part, d = ops.conv2d_forward(x, wt, None, 1, pad, dil, want_stats=False)
+    dy = torch.randn_like(y)
+    for _ in range(3):
+        ops.conv2d_backward_weight(dy, x, d)
+    torch.cuda.synchronize()
+    buf = np.zeros(8192 * 5, dtype=np.uint64)
+    lib.vspw_debug_nt_stamps(buf.ctypes.data, buf.size)
+    st = buf.reshape(-1, 5)
+    st = st[st[:, 0] > 0]
+    xcc = (st[:, 4] >> np.uint64(32)).astype(np.int64)
+    hwid = (st[:, 4] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    m = xcc == xcc[0]
+    t = st[m, :4].astype(np.int64)
+    keep = np.abs(t[:, 0] - np.median(t[:, 0])) < 4000000
+    t = t[keep]
+    t -= t[:, 0].min()
+    print("TN %s: %d WGs on one XCD; medians: prologue %d, loop %d, epilogue %d; span %d" % (
+        name, len(t), np.median(t[:, 1] - t[:, 0]), np.median(t[:, 2] - t[:, 1]), np.median(t[:, 3] - t[:, 2]),
+        t[:, 3].max()))
+    cu = (hwid >> 8) & 0xF; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 0x7
+    key = (se * 100 + sh * 20 + cu)[m][keep]
+    seq = t[key == key[0]]
+    seq = seq[np.argsort(seq[:, 0])]
+    for r in seq[:8]:
+        print("      %7d %7d %7d %7d" % tuple(r))
+
+
+run_tn("3x3 256 d2", 10, 60, 256, 256, 3, 2, 2)
+run_tn("1x1 256->1024", 10, 60, 256, 1024, 1, 0, 1)
+run_tn("1x1 1024->256", 10, 60, 1024, 256, 1, 0, 1)

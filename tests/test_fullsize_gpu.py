@@ -106,8 +106,8 @@ def test_cfg5_nonlocal3d_t7_and_netwarp_fullsize_properties(dev):
     g = torch.Generator().manual_seed(5)
     mod = build("nonlocal3d", "resnet101dilated").to(dev)
     mod.train()
-    imgs = [torch.randn(1, 3, S, S, generator=g).to(dev) for _ in range(7)]
-    labs = [torch.randint(0, K, (1, 1, S, S), generator=g).float().to(dev) for _ in range(7)]
+    imgs = [torch.randn(2, 3, S, S, generator=g).to(dev) for _ in range(7)]   # B = 2 clips, as BASELINE.json cfg 5b
+    labs = [torch.randint(0, K, (2, 1, S, S), generator=g).float().to(dev) for _ in range(7)]
     loss, acc = mod({"clipimgs_data": imgs, "cliplabels_data": labs})
     loss.backward()
     assert math.isfinite(loss.item())
@@ -129,6 +129,47 @@ def test_cfg5_nonlocal3d_t7_and_netwarp_fullsize_properties(dev):
     loss.backward()
     assert math.isfinite(loss.item())
     assert torch.isfinite(nw.w0_1.grad).all() and torch.isfinite(nw.flowcnn.conv1[0].weight.grad).all()
+
+
+def test_cfg5a_nonlocal2d_train_step_fullsize_properties(dev):
+    """cfg 5a: per-frame SegmentationModule with the Non_local2d decoder, R101, B = 2 at 479x479 (3 600 positions)."""
+    S = 479
+    g = torch.Generator().manual_seed(6)
+    mod = build("seg", "resnet101dilated", decoder="nonlocal2d", deep_sup_scale=None).to(dev)
+    mod.train()
+    img = torch.randn(2, 3, S, S, generator=g).to(dev)
+    lab = torch.randint(0, K, (2, 1, S, S), generator=g).float().to(dev)
+    loss, acc = mod({"img_data": img, "seg_label": lab})
+    loss.backward()
+    assert math.isfinite(loss.item()) and 0.0 <= float(acc) <= 1.0
+    grads = [p.grad for p in mod.parameters() if p.grad is not None]
+    assert len(grads) > 300 and all(torch.isfinite(gr).all() for gr in grads)
+
+
+def test_non_local_dot_values_at_cfg5b_size(dev):
+    """The fused affinity kernel at the T = 7 size (B = 2, N = 25 200 positions, C = 128; reference
+    models/non_local.py:105-143 would hold a 2.5 GB N x N tensor per sample): sampled output rows against float64
+    theta_i . phi^T . g / N, and the three gradients - which run through the same kernel with permuted operands -
+    against their float64 rows."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    B, N, C = 2, 25200, 128
+    g = torch.Generator().manual_seed(8)
+    q, k, v, dy = (torch.randn(B, N, C, generator=g).to(dev).requires_grad_(i < 3) for i in range(4))
+    out = ops.non_local_dot(q, k, v, 1.0 / N)
+    out.backward(dy)
+    rows = torch.randint(0, N, (48,), generator=g).to(dev)
+    q64, k64, v64, d64 = (t.detach().double() for t in (q, k, v, dy))
+    for b in range(B):
+        want = (q64[b, rows] @ k64[b].T) @ v64[b] / N
+        err = (out[b, rows].double() - want).abs().max().item()
+        assert err <= 2e-5 * max(want.abs().max().item(), 1e-3), ("y", b, err)
+        # d theta_i = (dy_i . g^T) phi / N ; d phi_j = (g_j . dy^T) theta / N ; d g_j = (phi_j . theta^T) dy / N
+        for name, got, a, m1, m2 in (("dq", q.grad, d64, v64, k64), ("dk", k.grad, v64, d64, q64),
+                                     ("dv", v.grad, k64, q64, d64)):
+            want = (a[b, rows] @ m1[b].T) @ m2[b] / N
+            err = (got[b, rows].double() - want).abs().max().item()
+            assert err <= 2e-5 * max(want.abs().max().item(), 1e-3), (name, b, err)
 
 
 @pytest.mark.parametrize("kind", ["clip_psp", "clip_ocr"])

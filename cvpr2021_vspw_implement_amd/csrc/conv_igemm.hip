@@ -363,7 +363,8 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
     IgemmNT p) {
     static_assert(TAPS == 0 || (NBUF == 1 && MODE != 2), "tap-inner order: single LDS buffer, non-pointwise");
     static_assert(!AFF || (MODE == 2 && NBUF == 1), "transformed A operand: pointwise, single LDS buffer");
-    // AFF 1: A = coef0*src + coef1*src2 + coef2 (BatchNorm-backward apply); AFF 2: A = relu(coef0*src + coef1 + src2)
+    // AFF 1: A = coef0*src + coef1*src2 + coef2 (BatchNorm-backward apply); AFF 2: A = relu(coef0*src + coef1 + src2);
+    // AFF 3: A = relu(coef0*src + coef1) (no residual)
     // (BatchNorm-forward apply + residual + ReLU of the producing node), also stored to zout
     NT_STAMP(0);
     NT_PRIO(NT_PRIO_EDGE);
@@ -409,12 +410,12 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char*>(wt0), 0, (int)(unsigned)(b_rem < (long long)NT_OOR ? b_rem : (long long)NT_OOR), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(AFF ? p.src2 + (size_t)img0 * p.h * p.w * p.lds : p.src)), 0,
+        const_cast<char*>(reinterpret_cast<const char*>((AFF == 1 || AFF == 2) ? p.src2 + (size_t)img0 * p.h * p.w * p.lds : p.src)), 0,
         (int)(unsigned)(a_rem < (long long)NT_OOR ? a_rem : (long long)NT_OOR), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(AFF ? p.coef : p.wt), 0, 3 * p.kdim * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(AFF == 2 ? p.zout + (size_t)img0 * p.h * p.w * p.lds : p.dst), 0,
+        reinterpret_cast<char*>(AFF >= 2 ? p.zout + (size_t)img0 * p.h * p.w * p.lds : p.dst), 0,
         (int)(unsigned)(a_rem < (long long)NT_OOR ? a_rem : (long long)NT_OOR), 0x00020000);
     // MODE 2 = pointwise at compile time (1x1, stride 1, no padding: source pixel == output pixel, every tap in the
     // image): no tap state, no in-image bits, no selects - the K loop is a plain GEMM loop
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
         }
     };
     f32x4 ra[RA], rb[RB];
-    f32x4 ra2[AFF ? RA : 1], cf[3];
+    f32x4 ra2[(AFF == 1 || AFF == 2) ? RA : 1], cf[3];
     int kb_regs = 0;  // k base of the tile currently held in the staging registers (AFF 2: where its z goes)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     auto load_tile = [&]() {
@@ -499,11 +500,13 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
             for (int i = 0; i < RA; ++i)
                 ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[i], cb * 4, 0));
             if (AFF) {
+                if (AFF != 3) {
 #pragma unroll
-                for (int i = 0; i < RA; ++i)
-                    ra2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a2, a_voff[i], cb * 4, 0));
+                    for (int i = 0; i < RA; ++i)
+                        ra2[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a2, a_voff[i], cb * 4, 0));
+                }
 #pragma unroll
-                for (int e = 0; e < (AFF == 2 ? 2 : 3); ++e)
+                for (int e = 0; e < (AFF >= 2 ? 2 : 3); ++e)
                     cf[e] = __builtin_bit_cast(
                         f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_c, (unsigned)(e * p.kdim + lcol) * 4u, kb * 4, 0));
                 kb_regs = kb;
@@ -518,11 +521,11 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
 #pragma unroll
             for (int i = 0; i < RA; ++i) ra[i] = cf[0] * ra[i] + (cf[1] * ra2[i] + cf[2]);
         }
-        if (AFF == 2) {  // same expression tree as bn_apply_kernel: (y*scale + shift) + residual, then ReLU
+        if (AFF >= 2) {  // same expression tree as bn_apply_kernel: (y*scale + shift) [+ residual], then ReLU
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 f32x4 v = ra[i] * cf[0] + cf[1];
-                v += ra2[i];
+                if (AFF == 2) v += ra2[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
                 ra[i] = v;
@@ -943,6 +946,10 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
     }
         if (p.src2 != nullptr && p.zout != nullptr) {  // fused forward apply of the producing node (A operand + z)
             NT_AFF_LAUNCH(2)
+            return;
+        }
+        if (p.zout != nullptr) {  // ... of a node without a residual branch
+            NT_AFF_LAUNCH(3)
             return;
         }
         if (p.src2 != nullptr) {  // affine A operand (fused BatchNorm-backward apply)
@@ -1764,7 +1771,7 @@ extern "C" size_t vspw_conv2d_fwd_apply_supported(const vspw_conv_desc* d) {
 extern "C" int vspw_conv2d_fwd_apply(const vspw_conv_desc* d, const float* y_in, const float* res_in,
                                      const float* scale_shift, float* z_out, const float* w, const float* bias, float* y,
                                      float* stat_part, void* stream) {
-    if (!conv_geometry_ok(d) || !y_in || !res_in || !scale_shift || !z_out || !w || !y) return VSPW_EINVAL;
+    if (!conv_geometry_ok(d) || !y_in || !scale_shift || !z_out || !w || !y) return VSPW_EINVAL;
     IgemmNT p;
     if (!fill_fwd_params(d, p)) return VSPW_EINVAL;
     bool v2;

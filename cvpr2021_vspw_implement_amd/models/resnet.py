@@ -5,6 +5,7 @@ Same constructor surface, attribute names and state_dict keys as the reference's
 executed as fused conv+BN(+residual)+ReLU kernel chains instead of separate ATen ops.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -25,6 +26,12 @@ def _residual_branch(block, x):
     if block.downsample is None:
         return x
     return vnn.conv_bn_act(x, block.downsample[0], block.downsample[1], relu=False)
+
+
+# conv2 -> conv3 hand-over of bn2 + ReLU (same mechanism as the block-output hand-over, no residual stream).  Measured
+# +-0 on the bench step (102.51 vs 102.58 ms: the 19 us bn_apply pass it removes costs as much as the 8-fold
+# re-evaluation in conv3's eight column tiles), so it is off by default; bit-identical either way (tests).
+_DEFER_CONV2 = os.environ.get("VSPW_FWD_APPLY_CONV2", "0") == "1"
 
 
 class _BlockSequential(nn.Sequential):
@@ -91,7 +98,8 @@ class Bottleneck(nn.Module):
             out, skip = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True, skip_out=True, fuse_input=sole_consumer)
         else:
             out = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
-        out = vnn.conv_bn_act(out, self.conv2, self.bn2, relu=True, fuse_input=True)   # conv1's output: only read here
+        # conv1's output is only read by conv2, conv2's only by conv3 (pointwise: it may evaluate bn2 + ReLU itself)
+        out = vnn.conv_bn_act(out, self.conv2, self.bn2, relu=True, fuse_input=True, defer_apply=_DEFER_CONV2)
         return vnn.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=_residual_branch(self, skip),
                                fuse_input=True, defer_apply=defer_output)
 

@@ -641,7 +641,7 @@ class ConvBNActFn(torch.autograd.Function):
         if residual is not None:
             residual = to_nhwc(residual)
         z = empty_nhwc(n, c, h, wd, dev)
-        if defer and out_link is not None and residual is not None and mask is None and relu and c % 32 == 0:
+        if defer and out_link is not None and mask is None and relu and c % 32 == 0:
             # z is written by its one reader (see _fwd_apply); everything that touches it later (this node's backward,
             # the reader's weight gradient, the next skip connection) runs after that reader on the same stream
             out_link.pending = (y, coef[2:], residual)

@@ -56,8 +56,9 @@ size_t vspw_conv2d_stats_partials(const vspw_conv_desc* d);
  * node that produced it (models/resnet.py:83-90 followed by the next Bottleneck's conv1, :75) - has NOT been
  * materialised: the GEMM evaluates it while staging its A operand (same expression tree as vspw_bn_apply: bit-identical
  * z) and writes it to z_out for the node's other readers (the skip connection, this conv's weight gradient, backward).
- * scale_shift: [2][c].  One pass over y_in / res_in instead of vspw_bn_apply's read-read-write followed by this conv's
- * read.  1x1, stride 1, no padding, c % 32 == 0 only (VSPW_EINVAL otherwise). */
+ * scale_shift: [2][c]; res_in may be NULL (a node without a residual branch: conv2 -> conv3 inside a Bottleneck,
+ * models/resnet.py:79-84).  One pass over y_in / res_in instead of vspw_bn_apply's read-read-write followed by this
+ * conv's read.  1x1, stride 1, no padding, c % 32 == 0 only (VSPW_EINVAL otherwise). */
 size_t vspw_conv2d_fwd_apply_supported(const vspw_conv_desc* d); /* 1 / 0 */
 int vspw_conv2d_fwd_apply(const vspw_conv_desc* d, const float* y_in, const float* res_in, const float* scale_shift,
                           float* z_out, const float* w, const float* bias, float* y, float* stat_part, void* stream);

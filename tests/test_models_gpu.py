@@ -465,9 +465,11 @@ def test_bn_backward_affine_operand_matches_materialised_dy(dev):
 
 def test_deferred_forward_apply_is_bit_identical(dev):
     """A bottleneck's final BatchNorm apply + skip + ReLU (reference models/resnet.py:83-90) evaluated inside the next
-    block's conv1 GEMM (vspw_conv2d_fwd_apply) against the separate apply pass: the same bits everywhere - loss, every
-    gradient, the running statistics - and the fused path is really taken (once per non-final bottleneck)."""
+    block's conv1 GEMM, and bn2 + ReLU evaluated inside conv3's (vspw_conv2d_fwd_apply), against the separate apply
+    passes: the same bits everywhere - loss, every gradient, the running statistics - and the fused path is really taken."""
     from cvpr2021_vspw_implement_amd import ops
+
+    from cvpr2021_vspw_implement_amd.models import resnet
 
     tag = "r50_clip_psp"
     inp = clip_inputs(tag, train_shape=(2, 3, 57, 57))
@@ -475,6 +477,7 @@ def test_deferred_forward_apply_is_bit_identical(dev):
     for fused in (True, False):
         ops._fwd_apply["enabled"] = fused
         ops._fwd_apply["nodes"] = 0
+        defer_conv2, resnet._DEFER_CONV2 = resnet._DEFER_CONV2, True  # exercise the optional conv2 -> conv3 hand-over too
         try:
             mod = build("clip_psp", "resnet50dilated")
             load_det(mod)
@@ -491,8 +494,10 @@ def test_deferred_forward_apply_is_bit_identical(dev):
             results.append((loss.item(), _grads(mod), stats, ops._fwd_apply["nodes"]))
         finally:
             ops._fwd_apply["enabled"] = True
+            resnet._DEFER_CONV2 = defer_conv2
     (l1, g1, s1, n1), (l0, g0, s0, n0) = results
-    assert n1 == (3 - 1) + (4 - 1) + (6 - 1) + (3 - 1) and n0 == 0, (n1, n0)
+    # conv2 -> conv3 inside each of the 16 bottlenecks, block output -> next conv1 for every non-final block of a layer
+    assert n1 == 16 + (3 - 1) + (4 - 1) + (6 - 1) + (3 - 1) and n0 == 0, (n1, n0)
     assert l1 == l0
     for k in g0:
         assert np.array_equal(g1[k], g0[k]), k

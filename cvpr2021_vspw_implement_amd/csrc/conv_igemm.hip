@@ -29,6 +29,7 @@
 
 #ifdef VSPW_NT_TIMING
 // DIAGNOSTIC build (-DVSPW_NT_TIMING): per-workgroup s_memtime stamps [start, after prologue, after K loop, end] + CU id
+// (-DVSPW_NT_TIMING=2: slot 1 is overwritten with "every store of the tile issued"); read by tools/diag/nt_phase.py
 __device__ unsigned long long vspw_nt_stamps[8192 * 5];
 #define NT_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 8192) vspw_nt_stamps[blockIdx.x * 5 + (i)] = __builtin_readcyclecounter()
 #define TN_STAMP(i)                                                                       \

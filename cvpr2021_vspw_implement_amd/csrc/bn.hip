@@ -95,18 +95,19 @@ __global__ __launch_bounds__(1024) void reduce_partials_kernel(const T* __restri
     }
 }
 
-// reduce the [tiles][2][c] fp32 partials of the conv epilogue AND finalise, one workgroup per 64 channels
+// reduce the [tiles][2][c] fp32 partials of the conv epilogue AND finalise, one workgroup per 32 channels (128-byte
+// rows) x 32 tile groups: these launches are pure latency - 375 tiles in 12 trips of 8 loads instead of 24
 __global__ __launch_bounds__(1024) void bn_finalize_partials_kernel(
     const float* __restrict__ part, int tiles, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
     float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift, int c) {
-    __shared__ double red[2][16][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + tx;
+    __shared__ double red[2][32][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + tx;
     double s = 0, q = 0;
     if (i < c) {
 #pragma unroll 8
-        for (int z = ty; z < tiles; z += 16) {  // unrolled: 16 independent loads in flight, same addition order
+        for (int z = ty; z < tiles; z += 32) {  // unrolled: 16 independent loads in flight, fixed addition order
             s += (double)part[(size_t)z * 2 * c + i];
             q += (double)part[(size_t)z * 2 * c + c + i];
         }
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_partials_kernel(
     if (ty != 0 || i >= c) return;
     s = q = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < 32; ++j) {
         s += red[0][j][tx];
         q += red[1][j][tx];
     }
@@ -145,21 +146,21 @@ template <typename T>
 __global__ __launch_bounds__(1024) void reduce_partials_pg_kernel(const T* __restrict__ part,
                                                                   double* __restrict__ sums, float* __restrict__ dgamma,
                                                                   float* __restrict__ dbeta, int splits, int c) {
-    __shared__ double red[16][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + tx;
+    __shared__ double red[32][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + tx;
     const int n = 2 * c;
     double a = 0;
     if (col < n) {
 #pragma unroll 8
-        for (int z = ty; z < splits; z += 16) a += (double)part[(size_t)z * n + col];
+        for (int z = ty; z < splits; z += 32) a += (double)part[(size_t)z * n + col];
     }
     red[ty][tx] = a;
     __syncthreads();
     if (ty == 0 && col < n) {
         double v = 0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v += red[j][tx];
+        for (int j = 0; j < 32; ++j) v += red[j][tx];
         sums[col] = v;
         if (col < c) {
             if (dbeta) dbeta[col] = (float)v;
@@ -494,7 +495,7 @@ extern "C" int vspw_bn_finalize_partials_f32(const float* part, int tiles, doubl
                                              float momentum, float eps, float* mean, float* invstd, float* scale,
                                              float* shift, int c, void* stream) {
     if (!part || tiles <= 0 || !mean || !invstd || !scale || !shift || c <= 0 || !(count > 0)) return VSPW_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(vspw_cdiv(c, 64)), dim3(1024), 0, vspw_stream(stream), part,
+    hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(vspw_cdiv(c, 32)), dim3(1024), 0, vspw_stream(stream), part,
                        tiles, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
                        c);
     return vspw_launch_status();
@@ -550,7 +551,7 @@ extern "C" int vspw_bn_bwd_reduce_pg(const float* dz, const float* z, const floa
     double* part = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(gx, gy), dim3(RED_TX, RED_TY), 0, vspw_stream(stream), dz, z, x, mean,
                        invstd, chan_mask, rows, c, rows_per_image, relu, part);
-    hipLaunchKernelGGL(reduce_partials_pg_kernel<double>, dim3(vspw_cdiv(2 * c, 64)), dim3(1024), 0,
+    hipLaunchKernelGGL(reduce_partials_pg_kernel<double>, dim3(vspw_cdiv(2 * c, 32)), dim3(1024), 0,
                        vspw_stream(stream), (const double*)part, sums, dgamma, dbeta, gy, c);
     return vspw_launch_status();
 }
@@ -558,7 +559,7 @@ extern "C" int vspw_bn_bwd_reduce_pg(const float* dz, const float* z, const floa
 extern "C" int vspw_bn_bwd_reduce_partials_f32(const float* part, int tiles, int c, double* sums, float* dgamma,
                                                float* dbeta, void* stream) {
     if (!part || !sums || tiles <= 0 || c <= 0) return VSPW_EINVAL;
-    hipLaunchKernelGGL(reduce_partials_pg_kernel<float>, dim3(vspw_cdiv(2 * c, 64)), dim3(1024), 0, vspw_stream(stream),
+    hipLaunchKernelGGL(reduce_partials_pg_kernel<float>, dim3(vspw_cdiv(2 * c, 32)), dim3(1024), 0, vspw_stream(stream),
                        part, sums, dgamma, dbeta, tiles, c);
     return vspw_launch_status();
 }

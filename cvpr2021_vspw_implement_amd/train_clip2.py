@@ -83,6 +83,57 @@ def make_batch(args, clip_imgs, clip_gts, it_):
     return batch_data
 
 
+class GraphedTrainStep(object):
+    """--hip_graph: the training step of `train` (zero_grad, forward, loss, backward, gradient all-reduce, SGD) captured
+    once as a hipGraph over static copies of the batch tensors and replayed per iteration (graph.GraphedStep).  The
+    capture needs warm-up executions of the step; parameters, buffers and momentum are snapshotted before and put back
+    after them, so the run takes exactly the reference's sequence of updates - and, every kernel being order-independent,
+    arrives at the same bits as the eager loop (tests/test_drivers_gpu.py).  Batches of another shape run eagerly."""
+
+    def __init__(self, module, optimizers, args, clip_imgs, clip_gts):
+        from . import ops
+        from .graph import GraphedStep
+
+        self.imgs = [t.clone() for t in clip_imgs]
+        self.gts = [t.clone() for t in clip_gts]
+        self.optimizers = optimizers
+        inner = module.module if hasattr(module, "module") else module
+        snap = {k: v.detach().clone() for k, v in inner.state_dict().items()}
+        had_momentum = {p: ("momentum_buffer" in optimizers.state[p]) for g in optimizers.param_groups
+                        for p in g["params"]}
+        mom = {p: optimizers.state[p]["momentum_buffer"].clone() for p, h in had_momentum.items() if h}
+
+        def step():
+            module.zero_grad()
+            loss, acc = module(make_batch(args, self.imgs, self.gts, 0))
+            loss, acc = loss.mean(), acc.mean()
+            loss.backward()
+            if hasattr(module, "finish_gradients"):
+                module.finish_gradients()
+            optimizers.step()
+            return loss, acc
+
+        self.graph = GraphedStep(step, warmup=2)
+        with torch.no_grad():
+            for k, v in inner.state_dict().items():
+                v.copy_(snap[k])
+            for p, h in had_momentum.items():
+                if "momentum_buffer" in optimizers.state[p]:
+                    buf = optimizers.state[p]["momentum_buffer"]
+                    buf.copy_(mom[p]) if h else buf.zero_()  # zero-filled buffers = torch's first-step semantics
+        ops.invalidate_inference_cache()
+
+    def matches(self, clip_imgs, clip_gts):
+        return (len(clip_imgs) == len(self.imgs) and all(a.shape == b.shape for a, b in zip(clip_imgs, self.imgs))
+                and all(a.shape == b.shape and a.dtype == b.dtype for a, b in zip(clip_gts, self.gts)))
+
+    def __call__(self, clip_imgs, clip_gts):
+        for dst, src in zip(self.imgs + self.gts, list(clip_imgs) + list(clip_gts)):
+            dst.copy_(src)
+        self.optimizers.set_lrs()
+        return self.graph.replay()
+
+
 def train(segmentation_module, data_loader, optimizers, history, epoch, cfg, args, transform=None, log=print):
     """One epoch: train_clip2.py:26-124."""
     batch_time, data_time = AverageMeter(), AverageMeter()
@@ -97,16 +148,22 @@ def train(segmentation_module, data_loader, optimizers, history, epoch, cfg, arg
         clip_imgs, clip_gts = transform(data) if transform is not None else data
         batch_data = make_batch(args, clip_imgs, clip_gts, it_)
         data_time.update(time.time() - tic)
-        segmentation_module.zero_grad()
         cur_iter = i + (epoch - 1) * epoch_iters
         adjust_learning_rate(optimizers, cur_iter, cfg, max_iters, args)
-        loss, acc = segmentation_module(batch_data)
-        loss = loss.mean()
-        acc = acc.mean()
-        loss.backward()
-        if hasattr(segmentation_module, "finish_gradients"):
-            segmentation_module.finish_gradients()  # wait for the bucketed RCCL all-reduce
-        optimizers.step()
+        graphed = getattr(args, "_graphed_step", None)
+        if getattr(args, "hip_graph", False) and graphed is None:
+            graphed = args._graphed_step = GraphedTrainStep(segmentation_module, optimizers, args, clip_imgs, clip_gts)
+        if graphed is not None and graphed.matches(clip_imgs, clip_gts):
+            loss, acc = graphed(clip_imgs, clip_gts)
+        else:
+            segmentation_module.zero_grad()
+            loss, acc = segmentation_module(batch_data)
+            loss = loss.mean()
+            acc = acc.mean()
+            loss.backward()
+            if hasattr(segmentation_module, "finish_gradients"):
+                segmentation_module.finish_gradients()  # wait for the bucketed RCCL all-reduce
+            optimizers.step()
         batch_time.update(time.time() - tic)
         tic = time.time()
         ave_total_loss.update(loss.data.item())
@@ -310,6 +367,9 @@ def build_parser():
     # additions (no reference counterpart): checkpoint period (the reference hard-codes 20, train_clip2.py:386) and the
     # RAFT checkpoint NetWarp loads (models/netwarp.py:72 hard-codes this path)
     p.add_argument("--ckpt_every", type=int, default=20)
+    p.add_argument("--hip_graph", action="store_true",
+                   help="replay the training step as one captured hipGraph (fixed crop / batch shapes; no reference "
+                        "counterpart)")
     p.add_argument("--raft_weights", type=str, default="./RAFT_core/raft-things.pth-no-zip")
     p.add_argument("opts", help="Modify config options using the command-line", default=None, nargs=argparse.REMAINDER)
     return p

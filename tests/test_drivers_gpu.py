@@ -101,3 +101,50 @@ def test_netwarp_train_step_with_hip_raft(dev, tree, tmp_path):
     cfg.MODEL.arch_encoder = "resnet50dilated"
     hist = T.main(cfg, [0], args)
     assert len(hist["train"]["loss"]) == 3 and all(np.isfinite(hist["train"]["loss"]))
+
+
+def test_hip_graph_training_loop_equals_the_eager_loop(dev, tree, tmp_path):
+    """train_clip2.train with --hip_graph (one captured hipGraph replayed per iteration over static batch buffers)
+    against the plain loop: same batches, same poly-LR schedule -> the same loss trace and bit-identical parameters,
+    buffers and momentum (Dropout2d disabled: warm-up executions of the capture advance the Philox offset, so masks
+    would differ; everything else is order-independent).  Also: the warm-up leaves no trace in the training state."""
+    import cvpr2021_vspw_implement_amd.train_clip2 as T
+    from helpers import load_det, zero_dropout
+
+    def run(hip_graph):
+        argv = ["--method", "clip_psp", "--dataroot", tree, "--saveroot", str(tmp_path / "g"), "--batchsize", "2",
+                "--cropsize", "40", "--clip_num", "4", "--dilation2", "3,6,9", "--totalepoch", "1", "--lr", "0.01",
+                "--workers", "0", "--gpus", "0"] + (["--hip_graph"] if hip_graph else [])
+        args = T.build_parser().parse_args(argv)
+        cfg = _cfg("ppm_deepsup_clip")
+        here = os.path.dirname(os.path.abspath(T.__file__))
+        args.cfg = os.path.join(here, "config", "vsp-resnet101dilated-ppm_deepsup_clip.yaml")
+        T.prepare(args, cfg)
+        cfg.MODEL.arch_encoder = "resnet50dilated"
+        cfg.TRAIN.num_epoch = 1
+        mod = T.build_module(cfg, args, args.num_class, training=True)
+        load_det(mod)
+        zero_dropout(mod)
+        mod.to(dev)
+        opt = T.create_optimizers(mod, cfg, args)
+        g = torch.Generator().manual_seed(11)
+        batches = []
+        for _ in range(4):   # 4 iterations of B = 2 clips x (1 + 3) frames
+            imgs = [torch.randn(2, 3, 40, 40, generator=g).to(dev) for _ in range(4)]
+            gts = [torch.randint(0, args.num_class, (2, 1, 40, 40), generator=g).float().to(dev) for _ in range(4)]
+            batches.append((imgs, gts))
+        hist = {"train": {"epoch": [], "loss": [], "acc": []}}
+        T.train(mod, batches, opt, hist, 1, cfg, args, transform=None, log=lambda *a: None)
+        torch.cuda.synchronize()
+        state = {k: v.detach().cpu().numpy() for k, v in mod.state_dict().items()}
+        mom = [opt.state[p]["momentum_buffer"].cpu().numpy() for grp in opt.param_groups for p in grp["params"]
+               if "momentum_buffer" in opt.state[p]]
+        return hist["train"]["loss"], state, mom, getattr(args, "_graphed_step", None)
+
+    l0, s0, m0, g0 = run(False)
+    l1, s1, m1, g1 = run(True)
+    assert g0 is None and g1 is not None
+    assert len(l0) == 4 and l0 == l1, (l0, l1)
+    for k in s0:
+        assert np.array_equal(s0[k], s1[k]), k
+    assert len(m0) == len(m1) and all(np.array_equal(a, b) for a, b in zip(m0, m1))

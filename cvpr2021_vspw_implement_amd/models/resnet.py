@@ -44,7 +44,9 @@ class _BlockSequential(nn.Sequential):
         for i, blk in enumerate(blocks):
             if isinstance(blk, Bottleneck):
                 # the next bottleneck's conv1 (pointwise) may evaluate this block's final BN + skip + ReLU itself
-                nxt = i + 1 < len(blocks) and isinstance(blocks[i + 1], Bottleneck)
+                # (not when a forward hook would look at the block's output before that conv1 has written it)
+                nxt = (i + 1 < len(blocks) and isinstance(blocks[i + 1], Bottleneck) and not blk._forward_hooks
+                       and not blocks[i + 1]._forward_pre_hooks)
                 x = blk(x, sole_consumer=i > 0, defer_output=nxt)
             else:
                 x = blk(x)

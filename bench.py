@@ -59,6 +59,13 @@ def parse_args():
     return ap.parse_args()
 
 
+# TEST MODE (tests/test_bench_gpu.py): VSPW_BENCH_SHARED_GPU=1 lets the N ranks of `--gpus N` share the visible device(s)
+# over the gloo backend (RCCL refuses two ranks on one GPU), so that the launcher, rendezvous, parameter broadcast,
+# SyncBN exchange, bucketed gradient averaging, max-over-ranks timing and rank-0 reporting of the N > 1 path run end to
+# end on a 1-GPU box.  The line it prints says so ("backend") and is not a performance measurement.
+SHARED_GPU_TEST = os.environ.get("VSPW_BENCH_SHARED_GPU") == "1"
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -72,7 +79,7 @@ def self_launch(n):
     import torch
 
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and not SHARED_GPU_TEST:
         raise RuntimeError("--gpus %d but only %d GPU(s) are visible (hipGetDeviceCount)" % (n, have))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -195,9 +202,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU fallback")
-    rank, local_rank, world = vdist.init_from_env()
+    rank, local_rank, world = vdist.init_from_env(backend="gloo" if SHARED_GPU_TEST else None)
     if world != args.gpus:
         raise RuntimeError("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if SHARED_GPU_TEST:
+        local_rank = local_rank % torch.cuda.device_count()
     if local_rank >= torch.cuda.device_count():
         raise RuntimeError("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank,
                                                                                  torch.cuda.device_count()))
@@ -242,6 +251,8 @@ def main():
 
     collectives = world > 1 or force
     mode = args.mode
+    if SHARED_GPU_TEST and collectives:
+        mode = "eager"  # gloo collectives stage through the host: not capturable
     if mode == "auto":
         mode = "graph"
         if collectives and not rccl_capture_preflight(dev):
@@ -374,8 +385,11 @@ def main():
                        "TCB-OCR (ClipOCRNet, resnet101dilated) train step: T=5, B=2/GPU, 479x479, 124 classes",
                        "global_batch_clips": world * B_CLIPS, "frames_per_step_per_gpu": T_FRAMES * B_CLIPS,
                        "parallelism": "dp%d" % world, "sync_bn": collectives,
-                       "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
-                       "execution": "hipGraph replay" if graphed is not None else "eager launches"},
+                       "rccl_ranks": 0 if SHARED_GPU_TEST else (
+                           torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
+                       "execution": "hipGraph replay" if graphed is not None else "eager launches",
+                       **({"backend": "gloo, ranks SHARING devices (VSPW_BENCH_SHARED_GPU test mode): plumbing check, "
+                                      "not a measurement"} if SHARED_GPU_TEST else {})},
             "e2e_mfma_frac": round(GFLOP_PER_CLIP * 1e9 * clips_per_s / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
             "last_loss": round(last_loss, 5),
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2),

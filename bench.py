@@ -63,7 +63,7 @@ def parse_args():
 # over the gloo backend (RCCL refuses two ranks on one GPU), so that the launcher, rendezvous, parameter broadcast,
 # SyncBN exchange, bucketed gradient averaging, max-over-ranks timing and rank-0 reporting of the N > 1 path run end to
 # end on a 1-GPU box.  The line it prints says so ("backend") and is not a performance measurement.
-SHARED_GPU_TEST = os.environ.get("VSPW_BENCH_SHARED_GPU") == "1"
+SHARED_GPU_TEST = os.environ.get("VSPW_BENCH_SHARED_GPU") == "1" or os.environ.get("VSPW_SHARED_GPU_TEST") == "1"
 
 
 def _free_port():
@@ -202,11 +202,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU fallback")
-    rank, local_rank, world = vdist.init_from_env(backend="gloo" if SHARED_GPU_TEST else None)
+    rank, local_rank, world = vdist.init_from_env()  # (test mode: gloo, LOCAL_RANK folded onto the visible devices)
     if world != args.gpus:
         raise RuntimeError("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if SHARED_GPU_TEST:
-        local_rank = local_rank % torch.cuda.device_count()
     if local_rank >= torch.cuda.device_count():
         raise RuntimeError("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank,
                                                                                  torch.cuda.device_count()))

@@ -17,11 +17,21 @@ import torch.distributed as dist
 from . import ops
 
 
+def shared_gpu_test():
+    """TEST MODE (tests/test_bench_gpu.py, tests/test_drivers_gpu.py): VSPW_SHARED_GPU_TEST=1 (or bench.py's
+    VSPW_BENCH_SHARED_GPU=1) lets several ranks share the visible device(s) over the gloo backend - RCCL refuses two
+    ranks on one GPU - so that the multi-rank host path can run end to end on a 1-GPU box.  Never a measurement."""
+    return os.environ.get("VSPW_SHARED_GPU_TEST") == "1" or os.environ.get("VSPW_BENCH_SHARED_GPU") == "1"
+
+
 def init_from_env(backend=None):
     """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if shared_gpu_test() and torch.cuda.is_available():
+        backend = backend or "gloo"
+        local_rank = local_rank % torch.cuda.device_count()
     if (world > 1 or os.environ.get("VSPW_FORCE_COLLECTIVES") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

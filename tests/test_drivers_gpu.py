@@ -148,3 +148,37 @@ def test_hip_graph_training_loop_equals_the_eager_loop(dev, tree, tmp_path):
     for k in s0:
         assert np.array_equal(s0[k], s1[k]), k
     assert len(m0) == len(m1) and all(np.array_equal(a, b) for a, b in zip(m0, m1))
+
+
+def test_two_rank_training_driver(dev, tree, tmp_path):
+    """train_clip2.main with WORLD_SIZE = 2 (torch.distributed.run; both ranks share the device over gloo in the
+    VSPW_SHARED_GPU_TEST mode - RCCL refuses two ranks on one GPU): DistributedSampler shards, parameter broadcast,
+    SyncBN + bucketed gradient averaging keep the replicas IDENTICAL, validation is sharded over the ranks with the
+    confusion matrices all-reduced (no rank left waiting in a collective), rank 0 alone writes the checkpoint."""
+    import subprocess
+    import sys
+
+    save = str(tmp_path / "ck2r")
+    os.makedirs(save)
+    env = dict(os.environ, VSPW_SHARED_GPU_TEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    here = os.path.dirname(os.path.abspath(__file__))
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(here, "two_rank_train_worker.py"), tree, save]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert r.stdout.count("Training Done!") == 1 and r.stdout.count("Saving checkpoints...") == 1   # rank 0 only
+    assert r.stdout.count("Validation:") == 1 and "mIoU" in r.stdout
+    assert os.path.exists(os.path.join(save, "model_epoch_2.pth"))
+    d0, d1 = (np.load(os.path.join(save, "rank%d_digest.npy" % k)) for k in (0, 1))
+    assert np.array_equal(d0, d1)                           # replicas in sync after two epochs (params AND BN buffers)
+    l0, l1 = (np.load(os.path.join(save, "rank%d_loss.npy" % k)) for k in (0, 1))
+    assert len(l0) == len(l1) == 2 and np.all(np.isfinite(l0)) and np.all(np.isfinite(l1))
+    assert not np.array_equal(l0, l1)                       # each rank trained on its own shard

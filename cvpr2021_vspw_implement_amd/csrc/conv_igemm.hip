@@ -76,6 +76,9 @@ struct IgemmNT {
     // (scale, shift); the A operand is evaluated while it is staged and - by the workgroups of the first column tile -
     // also written to zout ([m][lds], the tensor every later reader of z uses).
     float* zout;
+    // batched plain GEMM (vspw_bmm_nt): blockIdx.y = batch index, element strides of src / wt / dst between batches
+    int batch;
+    long long bs_src, bs_wt, bs_dst;
 #ifdef VSPW_NT_DBG
     int dbg;  // diagnostic builds only (tools/diag/nt_exposed.py): 1 = no epilogue memory traffic, 2 = no K loop
 #endif
@@ -120,7 +123,13 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 
 // WM x WN = MFMA 32x32 tiles per wave; 2x2 waves -> workgroup tile (64*WM) x (64*WN).
 template <int WM, int WN>
-__global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
+__global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT pin) {
+    IgemmNT p = pin;
+    if (pin.batch > 1) {
+        p.src += (size_t)blockIdx.y * pin.bs_src;
+        p.wt += (size_t)blockIdx.y * pin.bs_wt;
+        p.dst += (size_t)blockIdx.y * pin.bs_dst;
+    }
     constexpr int TM = 64 * WM, TN = 64 * WN;
     constexpr int RA = TM / 32, RB = TN / 32;  // rows staged per thread
     __shared__ __attribute__((aligned(16))) float As[TM * LDA];
@@ -361,7 +370,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT p) {
 
 template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, int AFF = 0>
 __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAPS == 0) ? 4 : ((NBUF == 1 && !(AFF && WM * WN > 3)) ? 3 : 2)) void igemm_nt_v2_kernel(
-    IgemmNT p) {
+    IgemmNT pin) {
+    IgemmNT p = pin;
+    if (pin.batch > 1) {
+        p.src += (size_t)blockIdx.y * pin.bs_src;
+        p.wt += (size_t)blockIdx.y * pin.bs_wt;
+        p.dst += (size_t)blockIdx.y * pin.bs_dst;
+    }
     static_assert(TAPS == 0 || (NBUF == 1 && MODE != 2), "tap-inner order: single LDS buffer, non-pointwise");
     static_assert(!AFF || (MODE == 2 && NBUF == 1), "transformed A operand: pointwise, single LDS buffer");
     // AFF 1: A = coef0*src + coef1*src2 + coef2 (BatchNorm-backward apply); AFF 2: A = relu(coef0*src + coef1 + src2);
@@ -931,19 +946,19 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
 #define NT_AFF_LAUNCH(A)                                                                                              \
     if (cfg == 22) {                                                                                                  \
         int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);                                                     \
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, 2, 1, 0, A>), dim3(tiles), dim3(256), 0, st, p);              \
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, 2, 1, 0, A>), dim3(tiles, p.batch), dim3(256), 0, st, p);              \
     } else if (cfg == 31) {                                                                                           \
         int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);                                                      \
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, 2, 1, 0, A>), dim3(tiles), dim3(256), 0, st, p);              \
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, 2, 1, 0, A>), dim3(tiles, p.batch), dim3(256), 0, st, p);              \
     } else if (cfg == 12) {                                                                                           \
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);                                                      \
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, 2, 1, 0, A>), dim3(tiles), dim3(256), 0, st, p);              \
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, 2, 1, 0, A>), dim3(tiles, p.batch), dim3(256), 0, st, p);              \
     } else if (cfg == 21) {                                                                                           \
         int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);                                                      \
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, 2, 1, 0, A>), dim3(tiles), dim3(256), 0, st, p);              \
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, 2, 1, 0, A>), dim3(tiles, p.batch), dim3(256), 0, st, p);              \
     } else {                                                                                                          \
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);                                                       \
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, 2, 1, 0, A>), dim3(tiles), dim3(256), 0, st, p);              \
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, 2, 1, 0, A>), dim3(tiles, p.batch), dim3(256), 0, st, p);              \
     }
         if (p.src2 != nullptr && p.zout != nullptr) {  // fused forward apply of the producing node (A operand + z)
             NT_AFF_LAUNCH(2)
@@ -964,19 +979,19 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
         if (tap_inner && p.kh == 3 && p.kw == 3) {  // 3x3: channel-slab-outer / tap-inner K order
             if (cfg == 22) {
                 int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
-                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 1, 9>), dim3(tiles), dim3(256), 0, st, p);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 1, 9>), dim3(tiles, p.batch), dim3(256), 0, st, p);
             } else if (cfg == 31) {
                 int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
-                hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, MODE, 1, 9>), dim3(tiles), dim3(256), 0, st, p);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, MODE, 1, 9>), dim3(tiles, p.batch), dim3(256), 0, st, p);
             } else if (cfg == 12) {
                 int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
-                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, MODE, 1, 9>), dim3(tiles), dim3(256), 0, st, p);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, MODE, 1, 9>), dim3(tiles, p.batch), dim3(256), 0, st, p);
             } else if (cfg == 21) {
                 int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);
-                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, MODE, 1, 9>), dim3(tiles), dim3(256), 0, st, p);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, MODE, 1, 9>), dim3(tiles, p.batch), dim3(256), 0, st, p);
             } else {
                 int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
-                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, MODE, 1, 9>), dim3(tiles), dim3(256), 0, st, p);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, MODE, 1, 9>), dim3(tiles, p.batch), dim3(256), 0, st, p);
             }
             return;
         }
@@ -987,21 +1002,21 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
         // single-buffer variant (3 workgroups/CU); long ones gain 2-5 % from the second buffer (one barrier per tile)
         static const int nbuf1_max_k = getenv("VSPW_NBUF1_MAXK") ? atoi(getenv("VSPW_NBUF1_MAXK")) : 1024;
         if (p.kdim <= nbuf1_max_k)
-            hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
+            hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
         else
-            hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 2>), dim3(tiles), dim3(256), 0, st, p);
+            hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 2>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     } else if (cfg == 31) {
         int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     } else if (cfg == 12) {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     } else if (cfg == 21) {
         int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     } else {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, MODE, 1>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     }
 }
 
@@ -1039,16 +1054,16 @@ static int launch_igemm_nt(const IgemmNT& p, hipStream_t st) {
     }
     if (cfg == 22) {
         int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
-        hipLaunchKernelGGL((igemm_nt_kernel<2, 2>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_kernel<2, 2>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     } else if (cfg == 12) {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
-        hipLaunchKernelGGL((igemm_nt_kernel<1, 2>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_kernel<1, 2>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     } else if (cfg == 21) {
         int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);
-        hipLaunchKernelGGL((igemm_nt_kernel<2, 1>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_kernel<2, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     } else {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
-        hipLaunchKernelGGL((igemm_nt_kernel<1, 1>), dim3(tiles), dim3(256), 0, st, p);
+        hipLaunchKernelGGL((igemm_nt_kernel<1, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     }
     return vspw_launch_status();
 }
@@ -1072,9 +1087,18 @@ struct IgemmTN {
     // gather mode 5 (pointwise + affine dY): dY element = coef[0][co]*dy + coef[1][co]*dy2 + coef[2][co]  (see IgemmNT)
     const float* dy2;
     const float* coef;
+    // batched plain GEMM (vspw_bmm_tn): blockIdx.z = batch index, element strides of dy / x / part between batches
+    int batch;
+    long long bs_dy, bs_x, bs_part;
 };
 
-__global__ __launch_bounds__(256) void igemm_tn_kernel(IgemmTN p) {
+__global__ __launch_bounds__(256) void igemm_tn_kernel(IgemmTN pin) {
+    IgemmTN p = pin;
+    if (pin.batch > 1) {
+        p.dy += (size_t)blockIdx.z * pin.bs_dy;
+        p.x += (size_t)blockIdx.z * pin.bs_x;
+        p.part += (size_t)blockIdx.z * pin.bs_part;
+    }
     __shared__ __attribute__((aligned(16))) float As[BK * BM];
     __shared__ __attribute__((aligned(16))) float Bs[BK * BN];
 
@@ -1224,7 +1248,13 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(IgemmTN p) {
 // Narrow weight matrices (Cout <= 64 or KH*KW*Cin <= 64: the stem, layer1, 1x1 convs to/from 64 channels) use
 // WM = 1 / WN = 1 so that no half of the MFMA tile is spent on padding.
 template <int G, int NBUF, int WM, int WN>
-__global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
+__global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN pin) {
+    IgemmTN p = pin;
+    if (pin.batch > 1) {
+        p.dy += (size_t)blockIdx.z * pin.bs_dy;
+        p.x += (size_t)blockIdx.z * pin.bs_x;
+        p.part += (size_t)blockIdx.z * pin.bs_part;
+    }
     TN_STAMP(0);
     NT_PRIO(NT_PRIO_EDGE);  // prologue / epilogue at raised priority (see NT_PRIO)
     constexpr bool LIN = G >= 2;
@@ -1586,6 +1616,8 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN p) {
 // dW = sum over split-K partial slabs (fixed order: deterministic).  float4 lanes, 4 slabs in flight per step.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                             long long n, int splits) {
+    part += (size_t)blockIdx.y * splits * n;  // batched GEMMs: one slab group and one output per blockIdx.y
+    out += (size_t)blockIdx.y * n;
     const long long n4 = (n & 3) ? 0 : (n >> 2);  // slabs are 16-B aligned only when n % 4 == 0
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -1725,6 +1757,7 @@ static bool fill_fwd_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr; p.addend = nullptr;
     p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
     p.src2 = nullptr; p.coef = nullptr; p.zout = nullptr;
+    p.batch = 1; p.bs_src = p.bs_wt = p.bs_dst = 0;
 #ifdef VSPW_NT_DBG
     p.dbg = getenv("VSPW_NT_DBG") ? atoi(getenv("VSPW_NT_DBG")) : 0;
 #endif
@@ -1865,6 +1898,7 @@ static bool fill_bwd_data_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.src = nullptr; p.wt = nullptr; p.bias = nullptr; p.dst = nullptr; p.stat_part = nullptr; p.addend = nullptr;
     p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
     p.src2 = nullptr; p.coef = nullptr; p.zout = nullptr;
+    p.batch = 1; p.bs_src = p.bs_wt = p.bs_dst = 0;
 #ifdef VSPW_NT_DBG
     p.dbg = getenv("VSPW_NT_DBG") ? atoi(getenv("VSPW_NT_DBG")) : 0;
 #endif
@@ -1921,12 +1955,12 @@ static void wgrad_tile(const vspw_conv_desc* d, int& tm, int& tn) {
 //   x (1 + 6 / k_tiles)                per-workgroup prologue + epilogue, about six K-tiles' worth
 //   + 100 * s / P                      partial slabs written and re-read (2 x 4 bytes per output element and split
 //                                      against 2 * P flops per output element at ~125 TFLOP/s and ~4 TB/s)
-static void wgrad_plan(const vspw_conv_desc* d, int& splits, int& chunk) {
+static void wgrad_plan(const vspw_conv_desc* d, int& splits, int& chunk, int batch = 1) {
     const long long P = (long long)d->n * d->oh * d->ow;
     const int ncols = d->kh * d->kw * d->c;
     int tm, tn;
     wgrad_tile(d, tm, tn);
-    const long long tiles = (long long)vspw_cdiv(d->k, tm) * vspw_cdiv(ncols, tn);
+    const long long tiles = (long long)vspw_cdiv(d->k, tm) * vspw_cdiv(ncols, tn) * batch;
     long long max_splits = (P + 255) / 256;
     if (max_splits > 512) max_splits = 512;
     if (max_splits < 1) max_splits = 1;
@@ -2002,8 +2036,12 @@ extern "C" size_t vspw_conv2d_bwd_weight_workspace(const vspw_conv_desc* d) {
     return (size_t)splits * d->k * d->kh * d->kw * d->c * sizeof(float);
 }
 
+struct BatchTN {  // vspw_bmm_tn: `batch` independent GEMMs, element strides between them
+    int batch;
+    long long bs_dy, bs_x, bs_out;
+};
 static int conv2d_bwd_weight_impl(const vspw_conv_desc* d, const float* dy, const float* x, float* dw, void* ws,
-                                  size_t ws_bytes, void* stream, const AffA* aff);
+                                  size_t ws_bytes, void* stream, const AffA* aff, const BatchTN* bt = nullptr);
 
 extern "C" int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, const float* x, float* dw,
                                       void* ws, size_t ws_bytes, void* stream) {
@@ -2018,9 +2056,11 @@ extern "C" int vspw_conv2d_bwd_weight_aff(const vspw_conv_desc* d, const float* 
 }
 
 static int conv2d_bwd_weight_impl(const vspw_conv_desc* d, const float* dy, const float* x, float* dw, void* ws,
-                                  size_t ws_bytes, void* stream, const AffA* aff) {
+                                  size_t ws_bytes, void* stream, const AffA* aff, const BatchTN* bt) {
     if (!conv_geometry_ok(d) || !dy || !x || !dw) return VSPW_EINVAL;
-    if (wgrad_pads_channels(d) && aff == nullptr) {
+    const int batch = bt ? bt->batch : 1;
+    if (batch < 1 || batch > 65535) return VSPW_EINVAL;
+    if (wgrad_pads_channels(d) && aff == nullptr && bt == nullptr) {
         vspw_conv_desc dp = *d;
         dp.c = (d->c + 3) & ~3;
         const size_t xb = align256((size_t)d->n * d->h * d->w * dp.c * sizeof(float));
@@ -2043,12 +2083,17 @@ static int conv2d_bwd_weight_impl(const vspw_conv_desc* d, const float* dy, cons
         return vspw_launch_status();
     }
     int splits, chunk;
-    wgrad_plan(d, splits, chunk);
-    size_t need = splits > 1 ? (size_t)splits * d->k * d->kh * d->kw * d->c * sizeof(float) : 0;
+    wgrad_plan(d, splits, chunk, batch);
+    const size_t out_elems = (size_t)d->k * d->kh * d->kw * d->c;
+    size_t need = splits > 1 ? (size_t)batch * splits * out_elems * sizeof(float) : 0;
     if (need > ws_bytes || (need > 0 && !ws)) return VSPW_EINVAL;
     IgemmTN p;
     p.dy = dy; p.x = x;
     p.part = splits > 1 ? reinterpret_cast<float*>(ws) : dw;
+    p.batch = batch;
+    p.bs_dy = bt ? bt->bs_dy : 0;
+    p.bs_x = bt ? bt->bs_x : 0;
+    p.bs_part = splits > 1 ? (long long)splits * (long long)out_elems : (bt ? bt->bs_out : 0);
     p.nb = d->n; p.h = d->h; p.w = d->w; p.c = d->c;
     p.oh = d->oh; p.ow = d->ow;
     p.kh = d->kh; p.kw = d->kw; p.stride = d->stride; p.pad = d->pad; p.padw = d->pad_w; p.dil = d->dil;
@@ -2067,7 +2112,7 @@ static int conv2d_bwd_weight_impl(const vspw_conv_desc* d, const float* dy, cons
     int tm, tn;
     wgrad_tile(d, tm, tn);
     if (!v2) tm = tn = 128;
-    const dim3 grid(vspw_cdiv(p.k, tm) * vspw_cdiv(p.ncols, tn), splits);
+    const dim3 grid(vspw_cdiv(p.k, tm) * vspw_cdiv(p.ncols, tn), splits, batch);
     hipStream_t st_ = vspw_stream(stream);
     if (aff) {
         // affine dY: pointwise, vector path, 128-row dY tiles and pixel chunks without a ragged last K-tile only
@@ -2105,11 +2150,54 @@ static int conv2d_bwd_weight_impl(const vspw_conv_desc* d, const float* dy, cons
     if (st != VSPW_OK) return st;
     if (splits > 1) {
         long long n = (long long)p.k * p.ncols;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(vspw_stream_grid(n / 4 + 1, 256)), dim3(256), 0, vspw_stream(stream),
-                           reinterpret_cast<const float*>(ws), dw, n, splits);
+        if (bt && bt->bs_out != n) return VSPW_EINVAL;  // (the batched reduce writes densely packed outputs)
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(vspw_stream_grid(n / 4 + 1, 256), batch), dim3(256), 0,
+                           vspw_stream(stream), reinterpret_cast<const float*>(ws), dw, n, splits);
         st = vspw_launch_status();
     }
     return st;
+}
+
+// ---- batched plain GEMMs (OCR object attention / gather, reference models/ocr_modules/spatial_ocr_block.py:100-109,
+// 252-274 torch.matmul / torch.bmm on [B, ., .] operands): the batch is a grid dimension of the SAME kernels
+static void bmm_nt_desc(vspw_conv_desc& d, int m, int n, int k) {
+    d.n = 1; d.h = m; d.w = 1; d.c = k; d.oh = m; d.ow = 1; d.k = n; d.kh = 1; d.kw = 1; d.stride = 1; d.pad = 0;
+    d.dil = 1; d.pad_w = 0;
+}
+
+extern "C" int vspw_bmm_nt(const float* a, const float* bt, float* c, int batch, int m, int n, int k, void* stream) {
+    if (!a || !bt || !c || batch < 1 || batch > 65535 || m < 1 || n < 1 || k < 1) return VSPW_EINVAL;
+    vspw_conv_desc d;
+    bmm_nt_desc(d, m, n, k);
+    IgemmNT p;
+    if (!conv_geometry_ok(&d) || !fill_fwd_params(&d, p)) return VSPW_EINVAL;
+    p.src = a; p.wt = bt; p.dst = c;
+    p.batch = batch;
+    p.bs_src = (long long)m * k; p.bs_wt = (long long)n * k; p.bs_dst = (long long)m * n;
+    return launch_igemm_nt(p, vspw_stream(stream));
+}
+
+static void bmm_tn_desc(vspw_conv_desc& d, int r, int m, int n) {
+    d.n = 1; d.h = r; d.w = 1; d.c = n; d.oh = r; d.ow = 1; d.k = m; d.kh = 1; d.kw = 1; d.stride = 1; d.pad = 0;
+    d.dil = 1; d.pad_w = 0;
+}
+
+extern "C" size_t vspw_bmm_tn_workspace(int batch, int r, int m, int n) {
+    if (batch < 1 || r < 1 || m < 1 || n < 1) return 0;
+    vspw_conv_desc d;
+    bmm_tn_desc(d, r, m, n);
+    int splits, chunk;
+    wgrad_plan(&d, splits, chunk, batch);
+    return splits > 1 ? (size_t)batch * splits * m * n * sizeof(float) : 0;
+}
+
+extern "C" int vspw_bmm_tn(const float* a, const float* b, float* c, int batch, int r, int m, int n, void* ws,
+                           size_t ws_bytes, void* stream) {
+    if (!a || !b || !c || batch < 1 || r < 1 || m < 1 || n < 1) return VSPW_EINVAL;
+    vspw_conv_desc d;
+    bmm_tn_desc(d, r, m, n);
+    BatchTN bt{batch, (long long)r * m, (long long)r * n, (long long)m * n};
+    return conv2d_bwd_weight_impl(&d, a, b, c, ws, ws_bytes, stream, nullptr, &bt);
 }
 
 extern "C" int vspw_weight_transpose(const float* w, float* wT, int k, int taps, int c, void* stream) {

@@ -1127,34 +1127,32 @@ def upsample_softmax(logits, size):
 
 
 # --------------------------------------------------------------------------------------------------- batched GEMMs
-def _gemm_nt(a, bt):
-    """a [M,K] row-major, bt [N,K] row-major -> a @ bt^T [M,N]   (1x1 conv forward kernel)."""
-    M, K = a.shape
-    N = bt.shape[0]
-    d = ConvDesc(1, M, 1, K, M, 1, N, 1, 1, 1, 0, 1)
-    y = torch.empty((M, N), device=a.device, dtype=torch.float32)
-    _C.call("vspw_conv2d_fwd", ctypes.byref(d), _p(a), _p(bt), None, _p(y), None, _stream())
-    return y
-
-
-def _gemm_tn(a, b):
-    """a [R,M], b [R,N] -> a^T @ b [M,N]   (1x1 conv weight-gradient kernel)."""
-    R, M = a.shape
-    N = b.shape[1]
-    d = ConvDesc(1, R, 1, N, R, 1, M, 1, 1, 1, 0, 1)
-    y = torch.empty((M, N), device=a.device, dtype=torch.float32)
-    nbytes = _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d))
-    ws = _ws(nbytes, a.device) if nbytes else None
-    _C.call("vspw_conv2d_bwd_weight", ctypes.byref(d), _p(a), _p(b), _p(y), _p(ws), nbytes, _stream())
-    return y
-
-
 def _transpose(a):
     """[B,R,C] -> [B,C,R] contiguous."""
     B, R, C = a.shape
     out = torch.empty((B, C, R), device=a.device, dtype=torch.float32)
     _C.call("vspw_transpose_batched", _p(a), _p(out), B, R, C, _stream())
     return out
+
+
+def _bmm_nt(a, bt):
+    """a [B,M,K], bt [B,N,K] (contiguous) -> [B,M,N]; the batch is a grid dimension of the pointwise-conv GEMM kernel."""
+    B, M, K = a.shape
+    N = bt.shape[1]
+    y = torch.empty((B, M, N), device=a.device, dtype=torch.float32)
+    _C.call("vspw_bmm_nt", _p(a), _p(bt), _p(y), B, M, N, K, _stream())
+    return y
+
+
+def _bmm_tn(a, b):
+    """a [B,R,M], b [B,R,N] (contiguous) -> a^T b [B,M,N]; batched split-R GEMM (the weight-gradient kernel)."""
+    B, R, M = a.shape
+    N = b.shape[2]
+    y = torch.empty((B, M, N), device=a.device, dtype=torch.float32)
+    nbytes = _C.query("vspw_bmm_tn_workspace", B, R, M, N)
+    ws = _ws(nbytes, a.device) if nbytes else None
+    _C.call("vspw_bmm_tn", _p(a), _p(b), _p(y), B, R, M, N, _p(ws), nbytes, _stream())
+    return y
 
 
 class BmmNTFn(torch.autograd.Function):
@@ -1166,19 +1164,17 @@ class BmmNTFn(torch.autograd.Function):
         a = a.contiguous()
         bt = bt.contiguous()
         ctx.save_for_backward(a, bt)
-        return torch.stack([_gemm_nt(a[i], bt[i]) for i in range(a.shape[0])], 0)
+        return _bmm_nt(a, bt)
 
     @staticmethod
     def backward(ctx, g):
         a, bt = ctx.saved_tensors
         g = g.contiguous()
-        B = a.shape[0]
         da = dbt = None
         if ctx.needs_input_grad[0]:  # da = g @ bt : NT with (bt^T) [K,N] rows
-            btT = _transpose(bt)  # [B,K,N]
-            da = torch.stack([_gemm_nt(g[i], btT[i]) for i in range(B)], 0)
+            da = _bmm_nt(g, _transpose(bt))
         if ctx.needs_input_grad[1]:  # dbt = g^T @ a  [N,K]
-            dbt = torch.stack([_gemm_tn(g[i], a[i]) for i in range(B)], 0)
+            dbt = _bmm_tn(g, a)
         return da, dbt
 
 
@@ -1191,19 +1187,17 @@ class BmmTNFn(torch.autograd.Function):
         a = a.contiguous()
         b = b.contiguous()
         ctx.save_for_backward(a, b)
-        return torch.stack([_gemm_tn(a[i], b[i]) for i in range(a.shape[0])], 0)
+        return _bmm_tn(a, b)
 
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
         g = g.contiguous()  # [B,M,N]
-        B = a.shape[0]
         da = db = None
         if ctx.needs_input_grad[0]:  # da [R,M] = b [R,N] @ g[M,N]^T
-            da = torch.stack([_gemm_nt(b[i], g[i]) for i in range(B)], 0)
+            da = _bmm_nt(b, g)
         if ctx.needs_input_grad[1]:  # db [R,N] = a [R,M] @ g [M,N] = NT(a, g^T [N,M])
-            gT = _transpose(g)
-            db = torch.stack([_gemm_nt(a[i], gT[i]) for i in range(B)], 0)
+            db = _bmm_nt(a, _transpose(g))
         return da, db
 
 

@@ -255,6 +255,14 @@ int vspw_zero_f64(double* p, long long n, void* stream);
 /* ---------------------------------------------------------------- misc (misc.hip) ----------------- */
 /* [b][r][c] -> [b][c][r] */
 int vspw_transpose_batched(const float* in, float* out, int b, int r, int c, void* stream);
+/* Batched plain GEMMs of the OCR object attention / context gather (models/ocr_modules/spatial_ocr_block.py:100-109,
+ * 252-274: torch.matmul / torch.bmm on [B, ., .] operands), all operands contiguous, the batch a grid dimension:
+ *   vspw_bmm_nt: c[b] = a[b] @ bt[b]^T     a [B][M][K], bt [B][N][K], c [B][M][N]
+ *   vspw_bmm_tn: c[b] = a[b]^T @ b_[b]     a [B][R][M], b_ [B][R][N], c [B][M][N]   (split over R, fixed-order sums) */
+int vspw_bmm_nt(const float* a, const float* bt, float* c, int batch, int m, int n, int k, void* stream);
+size_t vspw_bmm_tn_workspace(int batch, int r, int m, int n);
+int vspw_bmm_tn(const float* a, const float* b, float* c, int batch, int r, int m, int n, void* ws, size_t ws_bytes,
+                void* stream);
 /* colsum[c] = sum_rows a[row][c]  (bias gradients) */
 size_t vspw_colsum_workspace(long long rows, int c);
 int vspw_colsum(const float* a, float* out, long long rows, int c, void* ws, size_t ws_bytes, void* stream);

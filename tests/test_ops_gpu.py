@@ -372,6 +372,40 @@ def test_softmaxes_and_upsample_softmax(dev):
     assert (pd.argmax(1).cpu() == pr.argmax(1)).float().mean().item() > 0.999
 
 
+@pytest.mark.parametrize("B,M,N,K", [(5, 900, 124, 256),    # OCR attention scale: interior tiles, 5 batches in the grid
+                                     (3, 300, 256, 124),    # reduction over the 124 classes (K % 32 != 0: generic kernel)
+                                     (4, 1000, 512, 64)])
+def test_batched_gemms_at_ocr_sizes(dev, B, M, N, K):
+    """vspw_bmm_nt / vspw_bmm_tn (batch = grid dimension) against torch.matmul per batch, forward and both gradients."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(43 + N)
+    a = torch.randn(B, M, K, generator=g)
+    bt = torch.randn(B, N, K, generator=g)
+    gy = torch.randn(B, M, N, generator=g)
+    ar, br = a.clone().requires_grad_(True), bt.clone().requires_grad_(True)
+    (ar @ br.transpose(1, 2)).backward(gy)
+    ad, bd = a.to(dev).requires_grad_(True), bt.to(dev).requires_grad_(True)
+    yd = ops.bmm_nt(ad, bd)
+    yd.backward(gy.to(dev))
+    tol = 3e-5 * (K / 64.0) ** 0.5
+    _close(yd, a @ bt.transpose(1, 2), tol, "bmm_nt")
+    _close(ad.grad, ar.grad, 3e-5 * (N / 64.0) ** 0.5, "bmm_nt da")
+    _close(bd.grad, br.grad, 3e-5 * (M / 64.0) ** 0.5, "bmm_nt db")
+    # a^T b with the long dimension (pixels) as the reduction: split-R partial sums, batched reduce
+    pm = torch.randn(B, M, N, generator=g)
+    f = torch.randn(B, M, K, generator=g)
+    gz = torch.randn(B, N, K, generator=g)
+    pr, fr = pm.clone().requires_grad_(True), f.clone().requires_grad_(True)
+    (pr.transpose(1, 2) @ fr).backward(gz)
+    pd, fd = pm.to(dev).requires_grad_(True), f.to(dev).requires_grad_(True)
+    zd = ops.bmm_tn(pd, fd)
+    zd.backward(gz.to(dev))
+    _close(zd, pm.transpose(1, 2) @ f, 3e-5 * (M / 64.0) ** 0.5, "bmm_tn")
+    _close(pd.grad, pr.grad, 3e-5 * (K / 64.0) ** 0.5, "bmm_tn da")
+    _close(fd.grad, fr.grad, 3e-5 * (N / 64.0) ** 0.5, "bmm_tn db")
+
+
 def test_bmm_and_transpose(dev):
     from cvpr2021_vspw_implement_amd import ops
 

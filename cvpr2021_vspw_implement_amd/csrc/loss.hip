@@ -58,8 +58,11 @@ __global__ __launch_bounds__(256) void softmax_lastdim_bwd_kernel(const float* _
     }
 }
 
-#define SP_TX 32
-#define SP_TY 8
+// softmax over the pixels of each (sample, class) column of a [B][HW][K] tensor: 16 classes (64 bytes) x 64 row groups
+// per workgroup - the tensors are small (3 600 x 124 per sample) and the launch is latency-bound: 4 x 10 workgroups of
+// 8 row groups took 333 us forward / 260 us backward on the OCR bench step
+#define SP_TX 16
+#define SP_TY 64
 __global__ __launch_bounds__(SP_TX * SP_TY) void softmax_pixels_fwd_kernel(const float* __restrict__ x,
                                                                           float* __restrict__ y, int hw, int k,
                                                                           float alpha) {

@@ -277,10 +277,8 @@ class RAFT(nn.Module):
         f1 = fmap[:N]
         _C.call("vspw_axpby", _p(f1), _p(f1), f1.numel(), 1.0 / math.sqrt(256.0), 0.0, _stream())
         pyr = [torch.empty((rows, hw), **f32)]
-        for b in range(N):
-            d = ConvDesc(1, hw, 1, 256, hw, 1, hw, 1, 1, 1, 0, 1, 0)
-            _C.call("vspw_conv2d_fwd", ctypes.byref(d), _p(fmap[b]), _p(fmap[N + b]), None, _p(pyr[0][b * hw:]), None,
-                    _stream())
+        # corr[b] = fmap1[b] @ fmap2[b]^T for every pair in one batched launch
+        _C.call("vspw_bmm_nt", _p(fmap[:N]), _p(fmap[N:]), _p(pyr[0]), N, hw, hw, 256, _stream())
         lh, lw = h8, w8
         for _ in range(self.corr_levels - 1):
             nxt = torch.empty((rows, (lh // 2) * (lw // 2)), **f32)

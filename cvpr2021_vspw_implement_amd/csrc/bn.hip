@@ -141,6 +141,69 @@ __global__ __launch_bounds__(1024) void bn_finalize_partials_kernel(
     }
 }
 
+// Small populations (rows <= 1024: the 1x1 ... 6x6 pyramid-pool branches, the 124 object contexts of the OCR head):
+// statistics straight from the activations, TWO-PASS in fp64 (mean, then sum (x - mean)^2), and finalise in the same
+// launch.  The one-pass E[x^2] - mean^2 over fp32 tile partials of the conv epilogue loses (mean/std)^2 x 6e-8 of the
+// variance; with a population of 2 clips whose pooled features nearly coincide that ratio reaches 1e3-1e4 (measured on
+// the bench workload: the scale-1 PPM branch came out 4e-3 off in relative L2, 4x the float32 reference arithmetic).
+__global__ __launch_bounds__(256) void bn_small_finalize_kernel(
+    const float* __restrict__ x, int rows, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
+    double* __restrict__ sums, int c) {
+    __shared__ double red[8][32];
+    __shared__ double mu[32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + tx;
+    double s = 0;
+    if (i < c)
+        for (int r = ty; r < rows; r += 8) s += (double)x[(size_t)r * c + i];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0) {
+        s = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += red[j][tx];
+        mu[tx] = s;  // the LOCAL sum; with `sums` the caller exchanges it across ranks and finalises separately
+    }
+    __syncthreads();
+    const double lsum = mu[tx];
+    const double m = lsum / (double)rows;
+    double q = 0;
+    if (i < c)
+        for (int r = ty; r < rows; r += 8) {
+            const double d = (double)x[(size_t)r * c + i] - m;
+            q += d * d;
+        }
+    __syncthreads();
+    red[ty][tx] = q;
+    __syncthreads();
+    if (ty != 0 || i >= c) return;
+    q = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q += red[j][tx];
+    if (sums) {  // [sum x, sum x^2] for the cross-rank exchange (sum x^2 reassembled exactly enough in fp64)
+        sums[i] = lsum;
+        sums[c + i] = q + lsum * m;
+        return;
+    }
+    double var = q / count;
+    float mf = (float)m;
+    float is = (float)(1.0 / sqrt(var + (double)eps));
+    float g = gamma ? gamma[i] : 1.f;
+    float b = beta ? beta[i] : 0.f;
+    mean[i] = mf;
+    invstd[i] = is;
+    float sc = g * is;
+    scale[i] = sc;
+    shift[i] = b - mf * sc;
+    if (rmean) rmean[i] = (1.f - momentum) * rmean[i] + momentum * mf;
+    if (rvar) {
+        double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rvar[i] = (1.f - momentum) * rvar[i] + momentum * (float)unb;
+    }
+}
+
 // sums[i] = sum_z part[z][i] (fp64) and the fp32 parameter gradients dbeta = sums[0][:], dgamma = sums[1][:]
 template <typename T>
 __global__ __launch_bounds__(1024) void reduce_partials_pg_kernel(const T* __restrict__ part,
@@ -498,6 +561,17 @@ extern "C" int vspw_bn_finalize_partials_f32(const float* part, int tiles, doubl
     hipLaunchKernelGGL(bn_finalize_partials_kernel, dim3(vspw_cdiv(c, 32)), dim3(1024), 0, vspw_stream(stream), part,
                        tiles, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
                        c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_bn_small_finalize(const float* x, int rows, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                      float* invstd, float* scale, float* shift, double* sums, int c, void* stream) {
+    if (!x || rows <= 0 || rows > 1024 || c <= 0) return VSPW_EINVAL;
+    if (!sums && (!mean || !invstd || !scale || !shift)) return VSPW_EINVAL;
+    hipLaunchKernelGGL(bn_small_finalize_kernel, dim3(vspw_cdiv(c, 32)), dim3(256), 0, vspw_stream(stream), x, rows,
+                       (double)rows, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                       sums, c);
     return vspw_launch_status();
 }
 

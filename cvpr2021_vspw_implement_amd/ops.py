@@ -384,6 +384,9 @@ def conv2d(x, w, bias=None, stride=1, pad=0, dil=1):
 
 # --------------------------------------------------------------------------------------------------- batch norm
 _sync_group = {"enabled": False, "group": None, "force": False}
+# populations up to this many rows take their statistics two-pass in fp64 from the activations (see bn.hip:
+# bn_small_finalize_kernel) instead of from the convolution epilogue's fp32 tile partials
+_BN_SMALL_ROWS = 1024
 
 
 def set_sync_bn(enabled, group=None, force=False):
@@ -413,6 +416,19 @@ def _all_reduce_sums(sums):
     dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_sync_group["group"])
 
 
+# Decision tap (parity tests): ReLU and max-pool are the only non-smooth steps of the path.  When a list is installed
+# with record_decisions(), every training-path node that takes such a decision appends (kind, key tensor, output):
+# ("relu", the BatchNorm weight of the node, z) - z > 0 is the mask, read AFTER the forward pass has completed (a
+# deferred z is written by its consumer) - or ("maxpool", None, tap indices uint8 [n, oh, ow, c], ky*3+kx).  The test
+# injects them into the float64 oracle so that both differentiate the same branch of the network.
+_decisions = None
+
+
+def record_decisions(store):
+    global _decisions
+    _decisions = store
+
+
 class BatchNormActFn(torch.autograd.Function):
     """z = [relu](BN(x) [+ residual]) [* dropout2d mask]; training or eval statistics (csrc/bn.hip)."""
 
@@ -434,19 +450,27 @@ class BatchNormActFn(torch.autograd.Function):
                 raise ValueError("Expected more than 1 value per channel when training, got input size %s"
                                  % (tuple(x.shape),))
             _infer_fold["gen"] += 1  # running statistics are about to be rewritten in place
-            sums = torch.empty((2, c), device=dev, dtype=torch.float64)
-            if stat_part is not None:
-                _C.call("vspw_bn_reduce_partials_f32", _p(stat_part), stat_part.shape[0], c, _p(sums), st)
-            else:
-                nbytes = _C.query("vspw_bn_stats_workspace", rows, c)
-                ws = _ws(nbytes, dev)
-                _C.call("vspw_bn_stats", _p(x), rows, c, _p(sums), _p(ws), nbytes, st)
             world = _sync_world()
-            if world != 1:
-                _all_reduce_sums(sums)
-                count = float(rows * max(world, 1))
-            _C.call("vspw_bn_finalize", _p(sums), ctypes.c_double(count), _p(gamma), _p(beta), _p(running_mean),
-                    _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), c, st)
+            small = rows <= _BN_SMALL_ROWS
+            if small and world == 1:
+                _C.call("vspw_bn_small_finalize", _p(x), rows, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                        momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), None, c, st)
+            else:
+                sums = torch.empty((2, c), device=dev, dtype=torch.float64)
+                if small:
+                    _C.call("vspw_bn_small_finalize", _p(x), rows, None, None, None, None, momentum, eps, None, None,
+                            None, None, _p(sums), c, st)
+                elif stat_part is not None:
+                    _C.call("vspw_bn_reduce_partials_f32", _p(stat_part), stat_part.shape[0], c, _p(sums), st)
+                else:
+                    nbytes = _C.query("vspw_bn_stats_workspace", rows, c)
+                    ws = _ws(nbytes, dev)
+                    _C.call("vspw_bn_stats", _p(x), rows, c, _p(sums), _p(ws), nbytes, st)
+                if world != 1:
+                    _all_reduce_sums(sums)
+                    count = float(rows * max(world, 1))
+                _C.call("vspw_bn_finalize", _p(sums), ctypes.c_double(count), _p(gamma), _p(beta), _p(running_mean),
+                        _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), c, st)
         else:
             _C.call("vspw_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(mean),
                     _p(invstd), _p(scale), _p(shift), c, st)
@@ -494,8 +518,11 @@ class BatchNormActFn(torch.autograd.Function):
 
 def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, mask=None, training=True, momentum=0.1,
                    eps=1e-5, relu=False, stat_part=None):
-    return BatchNormActFn.apply(x, gamma, beta, running_mean, running_var, residual, mask, training, momentum, eps,
-                                relu, stat_part)
+    z = BatchNormActFn.apply(x, gamma, beta, running_mean, running_var, residual, mask, training, momentum, eps,
+                             relu, stat_part)
+    if _decisions is not None and relu:
+        _decisions.append(("relu", gamma, z))
+    return z
 
 
 _infer_fold = {"enabled": os.environ.get("VSPW_NO_INFER_FOLD", "0") != "1", "cache": {}, "gen": 0}
@@ -602,7 +629,9 @@ class ConvBNActFn(torch.autograd.Function):
                 momentum, eps, relu, skip_out=False, in_link=None, out_link=None, pending=None, defer=False):
         _require_gpu(x, "conv_bn_act")
         x = to_nhwc(x)
-        fuse_stats = training
+        dd = _conv_desc(x, w.shape[0], w.shape[2], w.shape[3], stride, pad, dil)
+        small = training and dd.n * dd.oh * dd.ow <= _BN_SMALL_ROWS  # exact two-pass statistics (vspw_bn_small_finalize)
+        fuse_stats = training and not small
         y, part, d = conv2d_forward(x, w, cbias, stride, pad, dil, want_stats=fuse_stats, pending=pending)
         n, c, h, wd = y.shape
         rows = n * h * wd
@@ -618,13 +647,19 @@ class ConvBNActFn(torch.autograd.Function):
                                  % (tuple(y.shape),))
             _infer_fold["gen"] += 1  # running statistics are about to be rewritten in place
             world = _sync_world()
-            if part is not None and world == 1:  # single rank: reduce the epilogue partials and finalise in one launch
+            if small and world == 1:
+                _C.call("vspw_bn_small_finalize", _p(y), rows, _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                        momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), None, c, st)
+            elif part is not None and world == 1:  # single rank: reduce the epilogue partials and finalise in one launch
                 _C.call("vspw_bn_finalize_partials_f32", _p(part), part.shape[0], ctypes.c_double(count), _p(gamma),
                         _p(beta), _p(running_mean), _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale),
                         _p(shift), c, st)
             else:
                 sums = torch.empty((2, c), device=dev, dtype=torch.float64)
-                if part is not None:
+                if small:
+                    _C.call("vspw_bn_small_finalize", _p(y), rows, None, None, None, None, momentum, eps, None, None,
+                            None, None, _p(sums), c, st)
+                elif part is not None:
                     _C.call("vspw_bn_reduce_partials_f32", _p(part), part.shape[0], c, _p(sums), st)
                 else:
                     nbytes = _C.query("vspw_bn_stats_workspace", rows, c)
@@ -782,6 +817,8 @@ def conv_bn_act(x, w, cbias, gamma, beta, running_mean, running_var, residual=No
     if pending is not None:
         x._vspw_pending = None  # written by the GEMM just launched
         _fwd_apply["nodes"] += 1
+    if _decisions is not None and relu:
+        _decisions.append(("relu", gamma, out[0] if skip_out else out))
     if out_link is not None and out_link.y is not None:
         z = out[0] if skip_out else out
         z._vspw_link = out_link
@@ -803,6 +840,8 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
         _C.call("vspw_maxpool3x3s2_fwd", _p(x), _p(y), _p(idx), n, h, w, c, oh, ow, _stream())
         ctx.shape = (n, c, h, w, oh, ow)
         ctx.save_for_backward(idx)
+        if _decisions is not None:
+            _decisions.append(("maxpool", None, idx))
         return y
 
     @staticmethod

@@ -137,6 +137,14 @@ int vspw_bn_reduce_partials_f32(const float* part, int tiles, int c, double* sum
 int vspw_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                      float* shift, int c, void* stream);
+/* Populations of at most 1024 rows (pyramid-pool branches, OCR object contexts; reference models/clip_psp.py:45-56,
+ * models/ocr_modules/spatial_ocr_block.py:247-289 through models/sync_batchnorm/batchnorm.py:70-73): statistics taken
+ * from the activations two-pass in fp64 and finalised in the same launch (what ATen's CPU batch_norm does in its double
+ * accumulators).  With sums != NULL the kernel only writes the local [sum x, sum x^2] (fp64) for the cross-rank
+ * exchange and the caller finalises with vspw_bn_finalize. */
+int vspw_bn_small_finalize(const float* x, int rows, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                           float* shift, double* sums, int c, void* stream);
 /* vspw_bn_reduce_partials_f32 + vspw_bn_finalize in one launch (single-rank training: no exchange in between). */
 int vspw_bn_finalize_partials_f32(const float* part, int tiles, double count, const float* gamma, const float* beta,
                                   float* running_mean, float* running_var, float momentum, float eps, float* mean,

@@ -42,7 +42,7 @@ def _bn(P, x, pre, training):
 
 def _cbr(P, x, conv, bn, training, stride=1, pad=0, dil=1, relu=True):
     y = _bn(P, _conv(P, x, conv, stride, pad, dil), bn, training)
-    return O.relu(y) if relu else y
+    return O.relu(y, key=bn) if relu else y
 
 
 def resnet_dilated(P, x, arch, pre, training):
@@ -52,7 +52,7 @@ def resnet_dilated(P, x, arch, pre, training):
     x = _cbr(P, x, pre + "conv1", pre + "bn1", training, 2, 1)
     x = _cbr(P, x, pre + "conv2", pre + "bn2", training, 1, 1)
     x = _cbr(P, x, pre + "conv3", pre + "bn3", training, 1, 1)
-    x = O.max_pool3x3s2(x)
+    x = O.max_pool3x3s2(x, key=pre + "maxpool")
     outs = []
     for li, nblocks in enumerate(layers):
         stage_stride = 1 if li == 0 else 2
@@ -76,12 +76,14 @@ def resnet_dilated(P, x, arch, pre, training):
                 y = _cbr(P, x, bp + "conv1", bp + "bn1", training)
                 y = _cbr(P, y, bp + "conv2", bp + "bn2", training, s3, p3, d3)
                 y = _cbr(P, y, bp + "conv3", bp + "bn3", training, relu=False)
+                last = bp + "bn3"
             else:
                 # BasicBlock: conv1 carries the stride (and is the one de-strided); conv2 is a plain 3x3 -> dilated
                 y = _cbr(P, x, bp + "conv1", bp + "bn1", training, s3, p3, d3)
                 d2 = dilate if dilate is not None else 1
                 y = _cbr(P, y, bp + "conv2", bp + "bn2", training, 1, d2, d2, relu=False)
-            x = O.relu(O.add(y, res))
+                last = bp + "bn2"
+            x = O.relu(O.add(y, res), key=last)  # the block's output ReLU, keyed by the BatchNorm that feeds it
         outs.append(x)
     return outs
 

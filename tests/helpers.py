@@ -161,3 +161,67 @@ def raft_state(fx):
     """Deterministic RAFT weights keyed by the reference's state_dict names (stored in the fixture)."""
     return {str(k): det_tensor(str(k), tuple(int(d) for d in str(s).split(",")) if str(s) else ())
             for k, s in zip(fx["sd_keys"], fx["sd_shapes"])}
+
+
+# ------------------------------------------------------------------------------------------------------ oracle jobs
+def run_oracle_jobs(jobs, workdir, parallel=None, threads=None, mem_gb=None):
+    """Run tests/oracle_worker.py once per job (a dict, see the worker) in separate processes that share the host:
+    at most `parallel` at a time (default: one per 16 CPUs), each with its share of the BLAS / OpenMP threads, and -
+    when the jobs carry a "mem_gb" estimate - never more than 60 % of the host's available memory (`mem_gb` overrides
+    the probe) committed at once.  job["after"] = index of a job that must have finished first (its decisions file).
+    Returns the loaded result npz per job (same order)."""
+    import json
+    import subprocess
+    import sys
+    import time
+
+    ncpu = os.cpu_count() or 8
+    if parallel is None:
+        parallel = max(1, min(len(jobs), ncpu // 16))
+    if threads is None:
+        threads = max(1, min(64, ncpu // parallel))
+    if mem_gb is None:
+        try:
+            import psutil
+
+            mem_gb = psutil.virtual_memory().available / 2 ** 30
+        except Exception:
+            mem_gb = 64.0
+    budget = 0.6 * mem_gb
+    env = dict(os.environ, OPENBLAS_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads), PYTHONDONTWRITEBYTECODE="1",
+               HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_worker.py")
+    pending = list(range(len(jobs)))
+    running, done = {}, set()
+    while pending or running:
+        used = sum(jobs[i].get("mem_gb", 0.0) for i in running)
+        for i in list(pending):
+            job = jobs[i]
+            if len(running) >= parallel:
+                break
+            if job.get("after") is not None and job["after"] not in done:
+                continue
+            if running and used + job.get("mem_gb", 0.0) > budget:
+                continue
+            pending.remove(i)
+            out = job.setdefault("out", os.path.join(workdir, "out%d.npz" % i))
+            jp = os.path.join(workdir, "job_%s.json" % os.path.basename(out))
+            with open(jp, "w") as f:
+                json.dump(job, f)
+            running[i] = subprocess.Popen([sys.executable, worker, jp], env=env)
+            used += job.get("mem_gb", 0.0)
+        for i, p in list(running.items()):
+            rc = p.poll()
+            if rc is None:
+                continue
+            del running[i]
+            if rc != 0:
+                for q in running.values():
+                    q.kill()
+                raise RuntimeError("oracle worker %d failed (rc %d): %r" % (i, rc, jobs[i]))
+            done.add(i)
+        if running:
+            time.sleep(0.2)
+        elif pending and all(jobs[i].get("after") is not None and jobs[i]["after"] not in done for i in pending):
+            raise RuntimeError("oracle jobs wait for jobs that never ran: %r" % pending)
+    return [np.load(job["out"]) for job in jobs]

@@ -181,6 +181,35 @@ def test_batchnorm_act(dev, shape, relu, res, train):
     _close(rv_d, rv_r, 1e-5, "running_var")
 
 
+@pytest.mark.parametrize("fused", [False, True])
+def test_batchnorm_tiny_population_with_nearly_equal_samples(dev, fused):
+    """PPM scale-1 branch: training-mode BatchNorm over B = 2 pooled vectors that nearly coincide (|a - b| ~ 1e-3 |a|;
+    reference models/clip_psp.py:45-56).  The variance is (a - b)^2 / 4, 1e6 times smaller than E[x^2]: a one-pass
+    E[x^2] - mean^2 over fp32 partials is off by percents there; with the two-pass fp64 statistics
+    (vspw_bn_small_finalize) the result is as close to float64 torch as float32 torch is (x2)."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    c = 512
+    a = torch.randn(1, c, 1, 1, generator=g) * 3
+    x = torch.cat([a, a * (1 + 1e-3 * torch.randn(1, c, 1, 1, generator=g))], 0)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    ref = F.batch_norm(x.double(), None, None, gamma.double(), beta.double(), True, 0.1, 1e-5)
+    rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+    if fused:  # through the conv + BN node: identity 1x1 convolution in front
+        w = torch.eye(c).reshape(c, c, 1, 1).to(dev)
+        y = ops.conv_bn_act(x.to(dev), w, None, gamma.to(dev), beta.to(dev), rm, rv, None, None, 1, 0, 1, True, 0.1,
+                            1e-5, False)
+    else:
+        y = ops.batch_norm_act(x.to(dev), gamma.to(dev), beta.to(dev), rm, rv, None, None, True, 0.1, 1e-5, False)
+    err = (y.double().cpu() - ref).norm() / ref.norm()
+    # yardstick: float32 storage of the mean alone costs |mean| / std x 6e-8 (ATen's own float32 result, below)
+    e32 = (F.batch_norm(x, None, None, gamma, beta, True, 0.1, 1e-5).double() - ref).norm() / ref.norm()
+    assert err < max(2.0 * e32, 1e-5), (err, e32)
+    var_u = x.double().var(0, unbiased=True).flatten()
+    assert ((rv.double().cpu() - (0.9 + 0.1 * var_u)).abs() / (0.9 + 0.1 * var_u)).max() < 1e-6
+
+
 def test_conv_bn_act_fused_and_dropout(dev):
     from cvpr2021_vspw_implement_amd import ops
 

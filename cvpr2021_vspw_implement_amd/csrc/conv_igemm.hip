@@ -2219,3 +2219,23 @@ extern "C" int vspw_nchw_to_nhwc(const float* in, float* out, int n, int c, long
                        out, n, c, hw);
     return vspw_launch_status();
 }
+
+// 1 when BOTH affine-operand gradient GEMMs (vspw_conv2d_bwd_data_aff, vspw_conv2d_bwd_weight_aff) accept this geometry;
+// callers fall back to vspw_bn_bwd_apply + the plain gradients otherwise.
+extern "C" size_t vspw_conv2d_bwd_aff_supported(const vspw_conv_desc* d) {
+    if (!conv_geometry_ok(d)) return 0;
+    const bool point = d->stride == 1 && d->oh == d->h && d->ow == d->w && d->kh * d->kw == 1 && d->pad == 0 &&
+                       d->pad_w == 0;
+    if (!point) return 0;
+    IgemmNT p;
+    if (!fill_bwd_data_params(d, p)) return 0;
+    bool v2;
+    nt_decide(p, v2);
+    if (!v2) return 0;
+    const long long P = (long long)d->n * d->oh * d->ow;
+    const bool tn_v2 = d->k % 4 == 0 && d->c % 4 == 0 && P * d->k < 0x7fffffffLL &&
+                       (long long)d->n * d->h * d->w * d->c < 0x7fffffffLL;
+    int tm, tn;
+    wgrad_tile(d, tm, tn);
+    return (tn_v2 && tm == 128 && P % BK == 0) ? 1 : 0;
+}

@@ -43,4 +43,10 @@ class GraphedStep(object):
 
     def replay(self):
         self.graph.replay()
+        # a replay rewrites parameters and BatchNorm running statistics through raw pointers: neither tensor._version
+        # nor the Python-side generation counters move, so the folded conv+BN weights cached for inference and the
+        # transposed weights of the data-gradient GEMMs would otherwise be reused stale by the next eager call
+        from . import ops
+
+        ops.invalidate_inference_cache()
         return self.outputs

@@ -331,7 +331,15 @@ def conv2d_backward_weight(dy, x, d, aff=None):
     # allocator cannot hand their memory to a later main-stream kernel while the side-stream GEMM still reads it
     # (dW itself must NOT be referenced here: with a second owner autograd's AccumulateGrad would clone it - a copy on
     # the main stream that races with the side-stream GEMM - instead of adopting the tensor as p.grad)
-    _wgrad_side["keep"].append((dy, x, ws, aff))
+    if torch.cuda.is_current_stream_capturing():
+        _wgrad_side["keep"].append((dy, x, ws, aff))  # graph-private pool: nothing is recycled before the join anyway
+    else:
+        # eager: tell the caching allocator that the side stream uses these blocks - each is recycled as soon as ITS
+        # GEMM has finished, so saved activations and dY tensors are released progressively during backward (a list
+        # held until the join kept the sum of all dY tensors + split-K workspaces of a backward pass alive)
+        for t in (dy, x, ws) + (tuple(aff) if aff is not None else ()):
+            if t is not None:
+                t.record_stream(side)
     if not _wgrad_side["dirty"]:
         _wgrad_side["dirty"] = True
         try:  # join when this backward pass ends, so that p.grad is safe to read on the main stream afterwards
@@ -735,8 +743,8 @@ class ConvBNActFn(torch.autograd.Function):
             if ctx.training and ctx.world != 1:
                 _all_reduce_sums(sums)
             pointwise = d.kh == 1 and d.kw == 1 and d.stride == 1 and d.pad == 0 and d.pad_w == 0
-            if (_bn_fusion["affine"] and pointwise and not ctx.has_cbias and d.c % 32 == 0 and c % 4 == 0
-                    and c >= _bn_fusion["affine_min_c"] and rows % 32 == 0):
+            if (_bn_fusion["affine"] and pointwise and not ctx.has_cbias and c >= _bn_fusion["affine_min_c"]
+                    and _C.query("vspw_conv2d_bwd_aff_supported", ctypes.byref(d)) == 1):
                 # pointwise conv: BatchNorm's backward apply becomes an affine map staged by the two gradient GEMMs of
                 # this conv - dy (the gradient w.r.t. the conv output) is never written
                 coef = torch.empty((3, c), device=dev, dtype=torch.float32)

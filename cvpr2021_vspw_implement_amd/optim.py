@@ -48,12 +48,10 @@ class SGD(torch.optim.Optimizer):
             g["mult"] = list(mult.values())
             groups.append(g)
         super().__init__(groups, defaults)
-        self._table_key = None
-        self._table = None
+        self._buckets = {}  # (momentum, device) -> {"key", "table", "pinned"}: one parameter table per launch
         self._lr_dev = None
         self._lr_host = None
         self._graph_keepalive = []
-        self._pinned = None
 
     def _collect(self):
         """[(momentum, device) -> [(p, g, buf, lr_slot, wd, mult)]]; momentum buffers are created zero-filled, which
@@ -94,6 +92,7 @@ class SGD(torch.optim.Optimizer):
         chunk = int(_C.query("vspw_sgd_chunk_elems"))
         capturing = torch.cuda.is_current_stream_capturing()
         lrs = np.asarray([float(g["lr"]) for g in self.param_groups], dtype=np.float32)
+        keep = []
         for (mom, dev), items in by_mom.items():
             if self._lr_dev is None or self._lr_dev.device != dev or self._lr_dev.numel() != lrs.size:
                 self._lr_dev = torch.zeros(lrs.size, device=dev, dtype=torch.float32)
@@ -109,28 +108,30 @@ class SGD(torch.optim.Optimizer):
                 n = p.numel()
                 rec[i] = (p.data_ptr(), g.data_ptr(), buf.data_ptr(), n, c0, 0.0, wd, mult, 0, slot, 0)
                 c0 += (n + chunk - 1) // chunk
-            key = (mom, dev, rec.tobytes())
-            if self._table_key != key:
+            bk = self._buckets.setdefault((mom, dev), {"key": None, "table": None, "pinned": None})
+            key = rec.tobytes()
+            if bk["key"] != key:
                 host = torch.from_numpy(rec.view(np.uint8).copy())
                 if capturing:
                     # a memcpy node needs a source that outlives the graph: a pinned staging buffer that was allocated
                     # by an earlier eager step (hipHostMalloc is not allowed while a stream is capturing)
-                    if self._pinned is None or self._pinned.numel() != host.numel():
+                    if bk["pinned"] is None or bk["pinned"].numel() != host.numel():
                         raise RuntimeError("vspw SGD: run at least one eager step before capturing a hipGraph")
-                    self._pinned.copy_(host)
-                    self._table = torch.empty(host.numel(), device=dev, dtype=torch.uint8)
-                    self._table.copy_(self._pinned, non_blocking=True)
-                    self._graph_keepalive.append((self._pinned, self._table))
-                    self._pinned = None  # owned by the graph from now on; a later capture stages through a new one
+                    bk["pinned"].copy_(host)
+                    bk["table"] = torch.empty(host.numel(), device=dev, dtype=torch.uint8)
+                    bk["table"].copy_(bk["pinned"], non_blocking=True)
+                    self._graph_keepalive.append((bk["pinned"], bk["table"]))
+                    bk["pinned"] = None  # owned by the graph from now on; a later capture stages through a new one
                 else:
-                    if self._pinned is None or self._pinned.numel() != host.numel():
-                        self._pinned = torch.empty(host.numel(), dtype=torch.uint8).pin_memory()
-                    self._table = host.to(dev)
-                self._table_key = key
-            _C.call("vspw_sgd_multi", ctypes.c_void_p(self._table.data_ptr()), len(items), c0, mom,
+                    if bk["pinned"] is None or bk["pinned"].numel() != host.numel():
+                        bk["pinned"] = torch.empty(host.numel(), dtype=torch.uint8).pin_memory()
+                    bk["table"] = host.to(dev)
+                bk["key"] = key
+            _C.call("vspw_sgd_multi", ctypes.c_void_p(bk["table"].data_ptr()), len(items), c0, mom,
                     ctypes.c_void_p(self._lr_dev.data_ptr()),
                     ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
-            self._keepalive = items  # until the next step: the launch is asynchronous
+            keep.append(items)
+        self._keepalive = keep  # until the next step: the launches are asynchronous
         ops.invalidate_inference_cache()  # folded conv+BN weights derive from the parameters just rewritten
         return loss
 

@@ -113,15 +113,18 @@ class GraphedTrainStep(object):
             optimizers.step()
             return loss, acc
 
-        self.graph = GraphedStep(step, warmup=2)
-        with torch.no_grad():
-            for k, v in inner.state_dict().items():
-                v.copy_(snap[k])
-            for p, h in had_momentum.items():
-                if "momentum_buffer" in optimizers.state[p]:
-                    buf = optimizers.state[p]["momentum_buffer"]
-                    buf.copy_(mom[p]) if h else buf.zero_()  # zero-filled buffers = torch's first-step semantics
-        ops.invalidate_inference_cache()
+        try:
+            self.graph = GraphedStep(step, warmup=2)
+        finally:  # also when the capture fails (an RCCL build that cannot be captured): the warm-up steps are undone
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for k, v in inner.state_dict().items():
+                    v.copy_(snap[k])
+                for p, h in had_momentum.items():
+                    if "momentum_buffer" in optimizers.state[p]:
+                        buf = optimizers.state[p]["momentum_buffer"]
+                        buf.copy_(mom[p]) if h else buf.zero_()  # zero-filled buffers = torch's first-step semantics
+            ops.invalidate_inference_cache()
 
     def matches(self, clip_imgs, clip_gts):
         return (len(clip_imgs) == len(self.imgs) and all(a.shape == b.shape for a, b in zip(clip_imgs, self.imgs))
@@ -152,7 +155,12 @@ def train(segmentation_module, data_loader, optimizers, history, epoch, cfg, arg
         adjust_learning_rate(optimizers, cur_iter, cfg, max_iters, args)
         graphed = getattr(args, "_graphed_step", None)
         if getattr(args, "hip_graph", False) and graphed is None:
-            graphed = args._graphed_step = GraphedTrainStep(segmentation_module, optimizers, args, clip_imgs, clip_gts)
+            try:
+                graphed = args._graphed_step = GraphedTrainStep(segmentation_module, optimizers, args, clip_imgs,
+                                                                clip_gts)
+            except Exception as e:  # state was restored by GraphedTrainStep: carry on launch by launch
+                log("hipGraph capture of the training step failed (%s: %s); running eagerly" % (type(e).__name__, e))
+                args.hip_graph = False
         if graphed is not None and graphed.matches(clip_imgs, clip_gts):
             loss, acc = graphed(clip_imgs, clip_gts)
         else:

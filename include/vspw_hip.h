@@ -107,6 +107,9 @@ int vspw_conv2d_bwd_data_aff(const vspw_conv_desc* d, const float* g, const floa
                              const float* bn_invstd, float* dx, float* stat_part, void* stream);
 int vspw_conv2d_bwd_weight_aff(const vspw_conv_desc* d, const float* g, const float* y, const float* coef, const float* x,
                                float* dw, void* ws, size_t ws_bytes, void* stream);
+/* 1 when both affine-operand gradients above accept the geometry (the caller otherwise applies the BatchNorm backward
+ * with vspw_bn_bwd_apply and runs the plain gradients). */
+size_t vspw_conv2d_bwd_aff_supported(const vspw_conv_desc* d);
 /* [k][taps][c] -> [c][taps][k] */
 int vspw_weight_transpose(const float* w, float* wT, int k, int taps, int c, void* stream);
 /* The same transpose for many weight tensors in ONE launch.  `entries` is a DEVICE array sorted by tile0 (= the sum of

@@ -57,7 +57,39 @@ def perturbed(a, seed, rel):
     return (a.astype(np.float64) * (1.0 + rel * rng.standard_normal(a.shape))).astype(np.float32)
 
 
+def eval_logits(job):
+    """mode "eval": inference logits (before the final up-sampling) of one 480p prediction as test_clip2.py runs it
+    (reference test_clip2.py:28-89): state dict from job["state"] (npz, calibrated running statistics included),
+    frames = det_input(job["tag"] + ":<t>"), the current frame LAST."""
+    from oracle import np_models as NM
+    from oracle import np_ops as O
+    from oracle.det_init import det_input
+
+    kind, arch, T = job["kind"], job["arch"], job["T"]
+    h, w = job["shape"]
+    dt = {"f32": np.float32, "f64": np.float64}[job["dtype"]]
+    z = np.load(job["state"])
+    t0 = time.time()
+    O.set_dtype(dt)
+    O.set_gemm(job.get("gemm", "blas"))
+    P = NM.Params({k: z[k].astype(dt) if z[k].dtype.kind == "f" else z[k] for k in z.files}, train_params=False)
+    frames = [det_input("%s:%d" % (job["tag"], t), (1, 3, h, w)).astype(dt) for t in range(T)]
+    if kind == "seg_ppm":  # per-frame PSPNet (reference models/models.py:938-995), logits of conv_last_
+        feats = NM.resnet_dilated(P, O.Var(frames[-1]), arch, "encoder.", False)
+        pooled = [O.adaptive_avg_pool2d(feats[-1], s) for s in (1, 2, 3, 6)]
+        x = NM._head(P, NM._ppm_concat(P, feats[-1], pooled, "decoder.ppm.", 1, 2, False), "decoder.conv_last_", False)
+    elif kind == "clip_psp":
+        _, x = NM.clip_psp(P, arch, frames, None, False, seg_size=(8, 8))
+    else:
+        _, x = NM.clip_ocr(P, arch, frames, None, False, seg_size=(8, 8))
+    O.set_gemm("blas")
+    O.set_dtype(np.float32)
+    np.savez(job["out"], logits=x.v.astype(np.float64), seconds=np.float64(time.time() - t0))
+
+
 def main(job):
+    if job.get("mode") == "eval":
+        return eval_logits(job)
     from helpers import K, build, det_numpy_state
     from oracle import np_models as NM
     from oracle import np_ops as O

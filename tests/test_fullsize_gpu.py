@@ -178,7 +178,7 @@ def test_non_local_dot_values_at_cfg5b_size(dev):
 # TCB-OCR, T = 5 frames, B = 2 clips, one training step at 239x239 crops (30x30 feature maps, BatchNorm populations of
 # 9 000) against the numpy oracle that tests/test_oracle_golden.py pins on the reference to 1e-9.
 #
-# Two questions, two tests, no hand-picked error factors:
+# Two questions, two tests; every gate is "no worse than 1.5x the float32 oracle put through the same procedure":
 #  (1) Is the HIP backward the gradient of the same function?  ReLU and max-pool are the only non-smooth steps; a unit
 #      whose pre-activation is a rounding error away from 0 flips between two implementations and moves EVERY upstream
 #      gradient (this made round 2's free comparison noisy: 3-7 % relative L2 between the reference's own float32 and
@@ -188,14 +188,22 @@ def test_non_local_dot_values_at_cfg5b_size(dev):
 #      What is left is NOT small - 100 random-weight layers amplify float32 rounding 1e4-fold in the forward pass
 #      (measured with tools/diag/pinned.py: 1e-7 after the first convolution, 6e-4 at the encoder output, identical for
 #      HIP and the float32 oracle) - so it is split in two:
-#        * the part of the error that REPRODUCES over two independent rounding realisations (step A on the inputs, step
-#          B on inputs perturbed by 1e-7 relative; each against its own decision-injected float64 run) -
-#          sqrt(<e_A, e_B>) / |g| - is what a wrong formula, a missing term or a mis-scaled factor produces: it must
-#          stay below 1e-3 relative L2 for every parameter;
-#        * the total error of either step must not exceed 1.5x that of the float32 ORACLE put through the same procedure
-#          (its own decisions, same two inputs), with the oracle's GEMMs in the accumulation order of a matrix-core
-#          k-loop (np_ops.set_gemm("sequential"): OpenBLAS, like the ATen kernels behind the reference, blocks the k
-#          loop, which is worth a factor 3 in rounding noise at K = 4 608 ... 36 864).
+#        * the total error of a step must not exceed 1.5x that of the float32 ORACLE put through the same procedure
+#          (its own decisions, same inputs), with the oracle's GEMMs in the accumulation order of a matrix-core k-loop
+#          (np_ops.set_gemm("sequential"): OpenBLAS, like the ATen kernels behind the reference, blocks the k loop,
+#          which is worth a factor 3 in rounding noise per GEMM at K = 4 608 ... 36 864; with it the oracle's forward
+#          error tracks HIP's to 2 % at every depth).  Two realisations each (step A on the inputs, step B on inputs
+#          perturbed by 1e-7 relative), the larger one counts on both sides: one oracle realisation differs from the
+#          next by up to 1.5x on its own;
+#        * the part of the error that REPRODUCES over the two realisations, sqrt(<e_A, e_B>) / |g| - what a wrong
+#          formula, a missing term or a mis-scaled factor would produce, but also every legitimate deterministic
+#          difference in float32 evaluation order, amplified like the rest (the oracle's own A/B errors correlate at
+#          0.24-0.31, HIP's at 0.40) - must stay below max(1e-3, 1.5x the oracle's reproducible part): the rule of
+#          helpers.logit_tol, 1e-3 unless the reference's arithmetic type is itself further than that from exact.
+#      Measured (R101, T=5, B=2, 239^2; per-parameter relative L2, median / p99 / max over the 340 / 358 tensors):
+#        TCB-PSP total HIP 1.6e-3 / 2.9e-3 / 3.7e-3, oracle 1.3e-3 / 2.3e-3 / 2.9e-3; reproducible 8.5e-4 / 1.5e-3 /
+#        2.0e-3 vs 5.3e-4 / 1.1e-3 / 1.5e-3.  TCB-OCR total 3.4e-3 / 7.2e-3 / 7.8e-3 vs 3.4e-3 / 7.6e-3 / 8.6e-3;
+#        reproducible 2.0e-3 / 4.4e-3 / 5.2e-3 vs 1.7e-3 / 4.0e-3 / 5.5e-3.  (Free comparison, for scale: 3e-2 ... 7e-2.)
 #  (2) Is the HIP step, compared freely against float64, one more realisation of float32 noise?  An ENSEMBLE of nine
 #      float32 oracle runs (the same sequential-order arithmetic; inputs perturbed by 1e-7 relative = one-ulp flips)
 #      measures that noise; HIP must lie within 1.5x of its worst member on every statistic.
@@ -310,9 +318,9 @@ def test_bench_workload_gradients_with_pinned_decisions(bench_case):
                           / max(np.linalg.norm(eh["A"][n][0]) * np.linalg.norm(eh["B"][n][0]), 1e-300) for n in names])
         np.savez(os.path.join(diag, "r03_pinned_%s.npz" % kind), names=np.array(names), hipA=rel(eh["A"]),
                  hipB=rel(eh["B"]), orA=rel(eo["A"]), orB=rel(eo["B"]), rep_h=rep_h, rep_o=rep_o, cos_h=cos_h, cos_o=cos_o)
-    assert np.median(tot_h) <= 1.5 * np.median(tot_o)
-    assert np.percentile(tot_h, 99) <= 1.5 * np.percentile(tot_o, 99)
-    assert tot_h.max() <= 1.5 * tot_o.max(), names[int(tot_h.argmax())]
+    for what, f in (("median", np.median), ("p99", lambda v: np.percentile(v, 99)), ("max", np.max)):
+        assert f(tot_h) <= 1.5 * f(tot_o), ("total", what, f(tot_h), f(tot_o))
+        assert f(rep_h) <= max(1e-3, 1.5 * f(rep_o)), ("reproducible", what, f(rep_h), f(rep_o))
 
 
 def test_bench_workload_against_fp32_ensemble(bench_case):

@@ -112,7 +112,7 @@ def test_eval_between_graph_replays_uses_current_weights(dev):
     ev = [_t(a, dev) for a in inp["eval_imgs"]]
     imgs = [_t(a, dev) for a in inp["train_imgs"]]
     labs = [_t(a, dev) for a in inp["train_labs"]]
-    opt = optim.create_optimizers(mod, lr=0.05, weight_decay=1e-4, momentum=0.9)
+    opt = optim.create_optimizers(mod, lr=0.01, weight_decay=1e-4, momentum=0.9)
 
     def predict():
         mod.eval()
@@ -140,5 +140,8 @@ def test_eval_between_graph_replays_uses_current_weights(dev):
         p1_unfolded = predict()
     finally:
         ops.set_inference_folding(True)
-    assert np.abs(p1 - p0).max() > 1e-4, "three SGD steps at lr 0.05 must change the prediction"
-    assert np.abs(p1 - p1_unfolded).max() < 2e-4, "folded inference path is stale after the graph replays"
+    change, gap = float(np.abs(p1 - p0).max()), float(np.abs(p1 - p1_unfolded).max())
+    print("prediction moved by %.3e over the replays; folded vs unfolded after them %.3e" % (change, gap))
+    assert change > 1e-4, "the replayed SGD steps must change the prediction"
+    # a stale cache reproduces the OLD weights in every conv+BN layer: the gap would be of the order of `change`
+    assert gap < 0.05 * change and gap < 1e-3, "folded inference path is stale after the graph replays"

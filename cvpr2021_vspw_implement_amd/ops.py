@@ -122,6 +122,42 @@ def _ws(nbytes, device):
 
 
 # --------------------------------------------------------------------------------------------------- conv
+# Winograd F(2x2,3x3) for stride-1 3x3 convolutions, forward and data gradient (csrc/winograd.hip): 4/9 of the direct
+# multiplications, run by the pointwise MFMA kernel as 16 batched GEMMs.  VSPW_WINOGRAD=0 switches back to the direct
+# implicit GEMM; VSPW_WINO_MINC = smallest channel count (both sides) that takes this path.
+_wino = {"enabled": os.environ.get("VSPW_WINOGRAD", "1") == "1", "min_c": int(os.environ.get("VSPW_WINO_MINC", "128")),
+         "launches": 0}
+
+
+def set_winograd(enabled):
+    _wino["enabled"] = bool(enabled)
+
+
+def _wino_ok(d):
+    return (_wino["enabled"] and d.kh == 3 and d.kw == 3 and d.stride == 1 and min(d.c, d.k) >= _wino["min_c"]
+            and _C.query("vspw_wino_supported", ctypes.byref(d)) == 1)
+
+
+def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, part=None, what="fwd"):
+    """dst = conv(src) through U, V, M (see winograd.hip); rows = output channels, reduce_c = channels of src."""
+    dev = src.device
+    st = _stream()
+    T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
+    u = torch.empty((16, rows, reduce_c), device=dev, dtype=torch.float32)
+    _C.call("vspw_wino_weights", _p(w), _p(u), d.k, d.c, 1 if data_gradient else 0, st)
+    v = torch.empty((16, T, reduce_c), device=dev, dtype=torch.float32)
+    _C.call("vspw_wino_input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
+    m = torch.empty((16, T, rows), device=dev, dtype=torch.float32)
+    with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-wino")):
+        _C.call("vspw_bmm_nt", _p(v), _p(u), _p(m), 16, T, rows, reduce_c, st)
+    z = y_ = mean = invstd = None
+    if front is not None:
+        z, y_, mean, invstd = front
+    _C.call("vspw_wino_output", ctypes.byref(d), _p(m), rows, _p(bias), _p(dst), _p(z), _p(y_), _p(mean), _p(invstd),
+            _p(part), st)
+    _wino["launches"] += 1
+
+
 def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None):
     """x NHWC-memory [N,C,H,W]; w [K,C,KH,KW] in channels_last memory ([K][KH][KW][C]).
     pending = (y_prev, scale_shift, residual): x has not been written yet - it is relu(scale*y_prev + shift +
@@ -136,6 +172,12 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None)
     d = _conv_desc(x, k, kh, kw, stride, pad, dil)
     y = empty_nhwc(d.n, k, d.oh, d.ow, x.device)
     part = None
+    if pending is None and _wino_ok(d):
+        if want_stats:
+            part = torch.empty((_C.query("vspw_wino_stat_partials", ctypes.byref(d)), 2, k), device=x.device,
+                               dtype=torch.float32)
+        _wino_conv(d, x, w, k, c, False, bias, y, part=part)
+        return y, part, d
     if want_stats:
         tiles = _C.query("vspw_conv2d_stats_partials", ctypes.byref(d))
         part = torch.empty((tiles, 2, k), device=x.device, dtype=torch.float32)
@@ -241,8 +283,19 @@ def conv2d_backward_data(dy, w, d, addend=None, bn_front=None, aff=None):
     aff = (y, coef): `dy` is really g, the gradient w.r.t. the BatchNorm OUTPUT; the GEMM stages
     coef[0]*g + coef[1]*y + coef[2] (BatchNorm's backward apply) as its operand (pointwise convs only)."""
     k, c, kh, kw = w.shape
-    wT = _transposed_weight(w)
     dx = empty_nhwc(d.n, d.c, d.h, d.w, dy.device)
+    if aff is None and addend is None and _wino_ok(d):
+        front = part = None
+        if bn_front is not None:
+            z, link = bn_front
+            front = (z, link.y, link.mean, link.invstd)
+            part = torch.empty((_C.query("vspw_wino_stat_partials", ctypes.byref(d)), 2, d.c), device=dy.device,
+                               dtype=torch.float32)
+        _wino_conv(d, dy, w, d.c, d.k, True, None, dx, front=front, part=part, what="dgrad")
+        if bn_front is not None:
+            link.partials, link.g = part, dx
+        return dx
+    wT = _transposed_weight(w)
     if aff is not None:
         y_, coef = aff
         if addend is not None:

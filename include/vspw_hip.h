@@ -110,6 +110,25 @@ int vspw_conv2d_bwd_weight_aff(const vspw_conv_desc* d, const float* g, const fl
 /* 1 when both affine-operand gradients above accept the geometry (the caller otherwise applies the BatchNorm backward
  * with vspw_bn_bwd_apply and runs the plain gradients). */
 size_t vspw_conv2d_bwd_aff_supported(const vspw_conv_desc* d);
+/* ---------------------------------------------------------------- Winograd F(2x2,3x3) (winograd.hip) --- */
+/* Stride-1 3x3 convolutions (pad == dilation; reference models/resnet.py:63-64 after models/models.py:737-750, heads
+ * models/clip_psp.py:29-35,74-79, models/clip_ocr.py:44-45) as 16 batched GEMMs with 4/9 of the direct multiplications:
+ *   U = vspw_wino_weights(w)            [16][rows][reduce]   (forward: rows = Cout; data gradient: rows = Cin, filter
+ *                                                              rotated by 180 degrees)
+ *   V = vspw_wino_input(x or dy)        [16][T][channels]    T = vspw_wino_tiles(d) (2x2 output tiles per image and
+ *                                                              dilation sub-grid)
+ *   M = vspw_bmm_nt(V, U, batch 16)     [16][T][rows]
+ *   y = vspw_wino_output(M)             NHWC, + bias; with stat_part: per-workgroup [2][channels] partial sums for the
+ *       BatchNorm that follows (vspw_wino_stat_partials(d) rows); with relu_src/bn_*: the BatchNorm-backward front end
+ *       of vspw_conv2d_bwd_data_bn.  `d` is the convolution's descriptor in every call (h, w, dil are used). */
+size_t vspw_wino_supported(const vspw_conv_desc* d);
+long long vspw_wino_tiles(const vspw_conv_desc* d);
+size_t vspw_wino_stat_partials(const vspw_conv_desc* d);
+int vspw_wino_weights(const float* w, float* u, int k, int c, int data_gradient, void* stream);
+int vspw_wino_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream);
+int vspw_wino_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
+                     const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
+                     float* stat_part, void* stream);
 /* [k][taps][c] -> [c][taps][k] */
 int vspw_weight_transpose(const float* w, float* wT, int k, int taps, int c, void* stream);
 /* The same transpose for many weight tensors in ONE launch.  `entries` is a DEVICE array sorted by tile0 (= the sum of

@@ -29,6 +29,11 @@ CONV_CASES = [
     (2, 4, 10, 12, 2, 3, 1, 1, 1, False),      # FlowCNN 4->2 (Cout=2)
     (2, 512, 12, 12, 256, 3, 1, 1, 1, True),   # bigger K: 4608 reduction
     (1, 124, 16, 16, 256, 1, 1, 0, 1, False),  # K=124 (not a multiple of 32)
+    # Winograd F(2x2,3x3) path (stride 1, >= 128 channels on both sides): odd sizes, dilation sub-grids with ragged tiles
+    (2, 128, 15, 15, 256, 3, 1, 4, 4, False),  # layer4 style: 4x4 sub-grids of 4x4 / 4x3 / 3x3 pixels
+    (2, 256, 13, 17, 128, 3, 1, 2, 2, True),   # layer3 style, bias
+    (3, 128, 9, 10, 128, 3, 1, 1, 1, False),   # undilated, one odd side
+    (1, 1024, 6, 7, 512, 3, 1, 1, 1, False),   # deepsup shape class: 9216-long direct reduction
 ]
 
 
@@ -59,6 +64,47 @@ def test_conv2d_fwd_bwd(dev, case):
     _close(wd.grad, wr.grad, 3e-6 * (n * yr.shape[2] * yr.shape[3]) ** 0.5 + 1e-5, "conv wgrad %s" % (case,))
     if bias:
         _close(bd.grad, br.grad, 1e-5, "conv bias grad %s" % (case,))
+
+
+@pytest.mark.parametrize("dil,h,w", [(1, 12, 13), (2, 14, 14), (4, 15, 15)])
+def test_winograd_path_equals_direct_path_in_a_fused_chain(dev, dil, h, w):
+    """1x1 conv+BN+ReLU -> 3x3 conv+BN+ReLU (fuse_input: the 3x3 data gradient carries the first node's BatchNorm-backward
+    front end) -> sum of squares: outputs, batch statistics (taken from the output transform's partial sums) and every
+    gradient with the Winograd path against the direct implicit GEMM.  Both are float32 evaluations of the same
+    expression, so they agree to rounding; also checks that the Winograd launches actually happened."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(77 + dil)
+    n, c0, c1, c2 = 2, 64, 128, 256
+    x = torch.randn(n, c0, h, w, generator=g)
+    w1 = torch.randn(c1, c0, 1, 1, generator=g) * 0.2
+    w2 = torch.randn(c2, c1, 3, 3, generator=g) * 0.05
+    res = []
+    for wino in (False, True):
+        ops.set_winograd(wino)
+        before = ops._wino["launches"]
+        try:
+            xd = x.to(dev).requires_grad_(True)
+            p1 = w1.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            p2 = w2.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            g1, b1 = torch.ones(c1, device=dev, requires_grad=True), torch.zeros(c1, device=dev, requires_grad=True)
+            g2, b2 = torch.ones(c2, device=dev, requires_grad=True), torch.zeros(c2, device=dev, requires_grad=True)
+            rm1, rv1, rm2, rv2 = (torch.zeros(c1, device=dev), torch.ones(c1, device=dev), torch.zeros(c2, device=dev),
+                                  torch.ones(c2, device=dev))
+            a = ops.conv_bn_act(xd, p1, None, g1, b1, rm1, rv1, None, None, 1, 0, 1, True, 0.1, 1e-5, True)
+            z = ops.conv_bn_act(a, p2, None, g2, b2, rm2, rv2, None, None, 1, dil, dil, True, 0.1, 1e-5, True, False,
+                                True)
+            (z * z).sum().backward()
+            torch.cuda.synchronize()
+            res.append([t.detach().float().cpu() for t in (z, rm2, rv2, xd.grad, p1.grad, p2.grad, g1.grad, b1.grad,
+                                                            g2.grad, b2.grad)])
+        finally:
+            ops.set_winograd(True)
+        assert (ops._wino["launches"] - before) == (2 if wino else 0)
+    names = ("z", "running_mean", "running_var", "dx", "dw1", "dw2", "dgamma1", "dbeta1", "dgamma2", "dbeta2")
+    for nm, a, b in zip(names, res[0], res[1]):
+        err = (a - b).norm() / b.norm().clamp_min(1e-12)
+        assert err < (2e-4 if nm in ("dbeta1", "dbeta2") else 2e-5), (nm, float(err))
 
 
 @pytest.mark.parametrize("n,c,h,w,k", [(2, 256, 16, 24, 64),   # interior 128x128 / 96-row tiles: accumulators seeded

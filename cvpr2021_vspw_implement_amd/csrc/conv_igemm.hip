@@ -913,9 +913,10 @@ extern "C" int vspw_debug_nt_stamps(unsigned long long* host_out, int n) {
 // out greedily, the busiest of the 256 CUs processes ceil(workgroups / 256) tiles.  Pick the tile height that
 // minimises  ceil(wg/256) * rows / efficiency  among 128 (2x2 waves of 2x2 MFMA tiles), 96 (1x4 waves of 3x1) and
 // 64 (2x2 waves of 1x2).  Codes: 22 / 31 / 12; narrow outputs (Cout <= 64, the stem) use 128x64 (21) or 64x64 (11).
-static int nt_pick_tile(long long m, int nout) {
-    if (nout <= 64) return (((m + 127) / 128) >= 1024) ? 21 : 11;
-    const long long tn = (nout + 127) / 128;
+static int nt_pick_tile(long long m, int nout, int batch = 1) {
+    if (batch < 1) batch = 1;
+    if (nout <= 64) return (((m + 127) / 128) * batch >= 1024) ? 21 : 11;
+    const long long tn = (long long)((nout + 127) / 128) * batch;  // batched GEMMs: the batch multiplies the grid
     // small problems (the RAFT update block: 12 840 pixels): with 64x128 tiles there would be at most two workgroups
     // per CU - one wave per SIMD, nothing to hide LDS / barrier latency behind.  64x64 tiles quadruple the number of
     // workgroups; the lost operand reuse does not matter at sizes that live in L2.
@@ -1025,7 +1026,7 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
 // measured (profiles/r01_*): the straight-line v2 pipeline wins 5-12 % everywhere; the 128x128 tile uses two LDS
 // buffers, the smaller tiles one (two would cap residency at 2 workgroups/CU and lose)
 static int nt_decide(const IgemmNT& p, bool& v2) {
-    int cfg = nt_pick_tile(p.m, p.nout);
+    int cfg = nt_pick_tile(p.m, p.nout, p.batch);
     // the fused BatchNorm-backward front end makes the epilogue a long memory phase (three extra operand streams): the
     // 96-row tile (48 accumulators, one more resident workgroup to overlap it with) beats 128x128 there (-10 %)
     if (p.relu_src != nullptr && cfg == 22) cfg = 31;

@@ -241,6 +241,79 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient
+// Y = A^T M A, M = U o V  =>  dM = A dY A^T,  dU[xi] = dM[xi]^T V[xi] (a TN GEMM over the tiles, vspw_bmm_tn, batch 16),
+// dg = G^T dU G.  A = [[1,0],[1,1],[1,-1],[0,-1]].  Output pixels outside the image (ragged tiles) carry no gradient.
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ dm, WinoGeom g,
+                                                      int K) {
+    const int k4n = K >> 2;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)g.T * k4n) return;
+    const int t = (int)(gid / k4n);
+    const int k = (int)(gid - (long long)t * k4n) * 4;
+    int img, sy, sx, ty, tx;
+    wino_tile(g, t, img, sy, sx, ty, tx);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 d[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int oy = (2 * ty + a) * g.d + sy;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ox = (2 * tx + b) * g.d + sx;
+            d[a][b] = (oy < g.h && ox < g.w)
+                          ? *reinterpret_cast<const f32x4*>(dy + (((size_t)img * g.h + oy) * g.w + ox) * K + k)
+                          : zero;
+        }
+    }
+    f32x4 r[4][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        r[0][b] = d[0][b];
+        r[1][b] = d[0][b] + d[1][b];
+        r[2][b] = d[0][b] - d[1][b];
+        r[3][b] = -d[1][b];
+    }
+    const size_t plane = (size_t)g.T * K;
+    float* out = dm + (size_t)t * K + k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        *reinterpret_cast<f32x4*>(out + (size_t)(i * 4 + 0) * plane) = r[i][0];
+        *reinterpret_cast<f32x4*>(out + (size_t)(i * 4 + 1) * plane) = r[i][0] + r[i][1];
+        *reinterpret_cast<f32x4*>(out + (size_t)(i * 4 + 2) * plane) = r[i][0] - r[i][1];
+        *reinterpret_cast<f32x4*>(out + (size_t)(i * 4 + 3) * plane) = -r[i][1];
+    }
+}
+
+// dW[k][ky][kx][c] = (G^T dU G)[ky][kx]; dU [16][K][C]; one thread per (k, 4 channels)
+__global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ du, float* __restrict__ dw, int K, int C) {
+    const int c4n = C >> 2;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)K * c4n) return;
+    const int k = (int)(gid / c4n);
+    const int c = (int)(gid - (long long)k * c4n) * 4;
+    const size_t plane = (size_t)K * C;
+    const float* in = du + (size_t)k * C + c;
+    f32x4 t[3][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const f32x4 u0 = *reinterpret_cast<const f32x4*>(in + (size_t)(0 * 4 + b) * plane);
+        const f32x4 u1 = *reinterpret_cast<const f32x4*>(in + (size_t)(1 * 4 + b) * plane);
+        const f32x4 u2 = *reinterpret_cast<const f32x4*>(in + (size_t)(2 * 4 + b) * plane);
+        const f32x4 u3 = *reinterpret_cast<const f32x4*>(in + (size_t)(3 * 4 + b) * plane);
+        t[0][b] = u0 + 0.5f * (u1 + u2);
+        t[1][b] = 0.5f * (u1 - u2);
+        t[2][b] = 0.5f * (u1 + u2) + u3;
+    }
+    float* out = dw + (size_t)k * 9 * C + c;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        *reinterpret_cast<f32x4*>(out + (size_t)(i * 3 + 0) * C) = t[i][0] + 0.5f * (t[i][1] + t[i][2]);
+        *reinterpret_cast<f32x4*>(out + (size_t)(i * 3 + 1) * C) = 0.5f * (t[i][1] - t[i][2]);
+        *reinterpret_cast<f32x4*>(out + (size_t)(i * 3 + 2) * C) = 0.5f * (t[i][1] + t[i][2]) + t[i][3];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 static int wino_cl4(int K) {
     const int k4 = K / 4;
@@ -298,5 +371,22 @@ extern "C" int vspw_wino_output(const vspw_conv_desc* d, const float* m, int cha
     else
         hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(256), 0, vspw_stream(stream), m, bias, y, nullptr, nullptr,
                            nullptr, nullptr, stat_part, g, channels, cl4);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_wino_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream) {
+    WinoGeom g;
+    if (!wino_geom(d, g) || !dy || !dm || channels <= 0 || channels % 4) return VSPW_EINVAL;
+    const long long items = (long long)g.T * (channels / 4);
+    hipLaunchKernelGGL(wino_dy_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), dy, dm, g,
+                       channels);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_wino_dw(const float* du, float* dw, int k, int c, void* stream) {
+    if (!du || !dw || k <= 0 || c <= 0 || c % 4) return VSPW_EINVAL;
+    const long long items = (long long)k * (c / 4);
+    hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), du, dw, k,
+                       c);
     return vspw_launch_status();
 }

@@ -126,7 +126,7 @@ def _ws(nbytes, device):
 # multiplications, run by the pointwise MFMA kernel as 16 batched GEMMs.  VSPW_WINOGRAD=0 switches back to the direct
 # implicit GEMM; VSPW_WINO_MINC = smallest channel count (both sides) that takes this path.
 _wino = {"enabled": os.environ.get("VSPW_WINOGRAD", "1") == "1", "min_c": int(os.environ.get("VSPW_WINO_MINC", "128")),
-         "launches": 0}
+         "wgrad": os.environ.get("VSPW_WINO_WGRAD", "1") == "1", "launches": 0}
 
 
 def set_winograd(enabled):
@@ -356,8 +356,28 @@ def join_side_streams():
         _wgrad_side["dirty"] = False
 
 
+def _wino_wgrad(dy, x, d, dw):
+    """dW of a stride-1 3x3 convolution in the Winograd domain (see winograd.hip): 4/9 of the direct multiplications."""
+    dev, st = dy.device, _stream()
+    T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
+    v = torch.empty((16, T, d.c), device=dev, dtype=torch.float32)
+    _C.call("vspw_wino_input", ctypes.byref(d), _p(x), d.c, _p(v), st)
+    dm = torch.empty((16, T, d.k), device=dev, dtype=torch.float32)
+    _C.call("vspw_wino_dy", ctypes.byref(d), _p(dy), d.k, _p(dm), st)
+    du = torch.empty((16, d.k, d.c), device=dev, dtype=torch.float32)
+    nbytes = _C.query("vspw_bmm_tn_workspace", 16, T, d.k, d.c)
+    ws = _ws(nbytes, dev) if nbytes else None
+    with _Timed("igemm_tn_kernel", 2.0 * 16 * T * d.k * d.c, _conv_tag(d, "wgrad-wino")):
+        _C.call("vspw_bmm_tn", _p(dm), _p(v), _p(du), 16, T, d.k, d.c, _p(ws), nbytes, st)
+    _C.call("vspw_wino_dw", _p(du), _p(dw), d.k, d.c, st)
+    _wino["launches"] += 1
+
+
 def _wgrad_launch(dy, x, d, aff=None):
     dw = torch.empty((d.k, d.kh, d.kw, d.c), device=dy.device, dtype=torch.float32).permute(0, 3, 1, 2)
+    if aff is None and _wino["wgrad"] and _wino_ok(d):
+        _wino_wgrad(dy, x, d, dw)
+        return dw, None
     nbytes = _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d))
     ws = _ws(nbytes, dy.device) if nbytes else None
     with _Timed("igemm_tn_kernel", _conv_flops(d), _conv_tag(d, "wgrad")):

@@ -129,6 +129,10 @@ int vspw_wino_input(const vspw_conv_desc* d, const float* x, int channels, float
 int vspw_wino_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
                      const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
                      float* stat_part, void* stream);
+/* Weight gradient in the transform domain: dM = vspw_wino_dy(dY) [16][T][Cout]; dU = vspw_bmm_tn(dM, V, batch 16)
+ * [16][Cout][Cin] with V = vspw_wino_input(x); dW = vspw_wino_dw(dU) in the weight layout [Cout][3][3][Cin]. */
+int vspw_wino_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream);
+int vspw_wino_dw(const float* du, float* dw, int k, int c, void* stream);
 /* [k][taps][c] -> [c][taps][k] */
 int vspw_weight_transpose(const float* w, float* wT, int k, int taps, int c, void* stream);
 /* The same transpose for many weight tensors in ONE launch.  `entries` is a DEVICE array sorted by tile0 (= the sum of

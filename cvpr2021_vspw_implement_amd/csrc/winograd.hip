@@ -75,10 +75,10 @@ __device__ __forceinline__ void wino_g(const float g[9], float u[16]) {
     }
 }
 
-__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int K,
-                                                          int C, int mode) {
+// modes: bit 0 = forward transform into u, bit 1 = data-gradient transform into u2
+__device__ __forceinline__ void wino_weight_tile(const float* __restrict__ w, float* __restrict__ u,
+                                                 float* __restrict__ u2, int K, int C, int modes, int c0, int k0) {
     __shared__ float gs[9][32][33];  // [tap][k][c]
-    const int c0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     for (int kk = ty; kk < 32; kk += 8) {
         const int k = k0 + kk, c = c0 + tx;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
     const size_t plane = (size_t)K * C;
     for (int rr = ty; rr < 32; rr += 8) {
         float g[9], uu[16];
-        if (mode == 0) {  // row = k (rr), column = c (tx): coalesced along c
+        if (modes & 1) {  // row = k (rr), column = c (tx): coalesced along c
 #pragma unroll
             for (int t = 0; t < 9; ++t) g[t] = gs[t][rr][tx];
             wino_g(g, uu);
@@ -97,16 +97,41 @@ __global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restric
             if (k < K && c < C)
 #pragma unroll
                 for (int x = 0; x < 16; ++x) u[x * plane + (size_t)k * C + c] = uu[x];
-        } else {  // row = c (rr), column = k (tx): coalesced along k; filter rotated by 180 degrees
+        }
+        if (modes & 2) {  // row = c (rr), column = k (tx): coalesced along k; filter rotated by 180 degrees
 #pragma unroll
             for (int t = 0; t < 9; ++t) g[t] = gs[8 - t][tx][rr];
             wino_g(g, uu);
             const int c = c0 + rr, k = k0 + tx;
             if (k < K && c < C)
 #pragma unroll
-                for (int x = 0; x < 16; ++x) u[x * plane + (size_t)c * K + k] = uu[x];
+                for (int x = 0; x < 16; ++x) u2[x * plane + (size_t)c * K + k] = uu[x];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int K,
+                                                          int C, int mode) {
+    wino_weight_tile(w, u, u, K, C, mode == 0 ? 1 : 2, blockIdx.x * 32, blockIdx.y * 32);
+}
+
+// Both transforms of MANY weight tensors in one launch (they all go stale together, at the optimizer step): entries[]
+// (device, sorted by tile0 = number of 32x32 (k, c) tiles of all preceding tensors); entry.wT -> [2][16][K*C]
+// (forward transform, then data-gradient transform).
+__global__ __launch_bounds__(256) void wino_weight_multi_kernel(const vspw_wt_entry* __restrict__ entries, int n_entries) {
+    const long long b = blockIdx.x;
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (entries[mid].tile0 <= b)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const vspw_wt_entry e = entries[lo];
+    const int local = (int)(b - e.tile0);
+    const int tc = (e.c + 31) / 32;
+    wino_weight_tile(e.w, e.wT, e.wT + (size_t)16 * e.k * e.c, e.k, e.c, 3, (local % tc) * 32, (local / tc) * 32);
 }
 
 // ------------------------------------------------------------------------------------------------ input
@@ -388,5 +413,14 @@ extern "C" int vspw_wino_dw(const float* du, float* dw, int k, int c, void* stre
     const long long items = (long long)k * (c / 4);
     hipLaunchKernelGGL(wino_dw_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), du, dw, k,
                        c);
+    return vspw_launch_status();
+}
+
+extern "C" long long vspw_wino_weight_tiles(int k, int c) { return (long long)vspw_cdiv(k, 32) * vspw_cdiv(c, 32); }
+
+extern "C" int vspw_wino_weights_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream) {
+    if (!entries || n_entries <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffffLL) return VSPW_EINVAL;
+    hipLaunchKernelGGL(wino_weight_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, vspw_stream(stream), entries,
+                       n_entries);
     return vspw_launch_status();
 }

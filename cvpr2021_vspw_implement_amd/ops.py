@@ -126,7 +126,8 @@ def _ws(nbytes, device):
 # multiplications, run by the pointwise MFMA kernel as 16 batched GEMMs.  VSPW_WINOGRAD=0 switches back to the direct
 # implicit GEMM; VSPW_WINO_MINC = smallest channel count (both sides) that takes this path.
 _wino = {"enabled": os.environ.get("VSPW_WINOGRAD", "1") == "1", "min_c": int(os.environ.get("VSPW_WINO_MINC", "128")),
-         "wgrad": os.environ.get("VSPW_WINO_WGRAD", "1") == "1", "launches": 0}
+         "wgrad": os.environ.get("VSPW_WINO_WGRAD", "1") == "1", "launches": 0,
+         "keep_v": os.environ.get("VSPW_WINO_KEEP_V", "1") == "1"}
 
 
 def set_winograd(enabled):
@@ -143,8 +144,7 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
     dev = src.device
     st = _stream()
     T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
-    u = torch.empty((16, rows, reduce_c), device=dev, dtype=torch.float32)
-    _C.call("vspw_wino_weights", _p(w), _p(u), d.k, d.c, 1 if data_gradient else 0, st)
+    u = _wino_weights(w, data_gradient)
     v = torch.empty((16, T, reduce_c), device=dev, dtype=torch.float32)
     _C.call("vspw_wino_input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
     m = torch.empty((16, T, rows), device=dev, dtype=torch.float32)
@@ -156,6 +156,7 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
     _C.call("vspw_wino_output", ctypes.byref(d), _p(m), rows, _p(bias), _p(dst), _p(z), _p(y_), _p(mean), _p(invstd),
             _p(part), st)
     _wino["launches"] += 1
+    return v
 
 
 def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None):
@@ -176,7 +177,10 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None)
         if want_stats:
             part = torch.empty((_C.query("vspw_wino_stat_partials", ctypes.byref(d)), 2, k), device=x.device,
                                dtype=torch.float32)
-        _wino_conv(d, x, w, k, c, False, bias, y, part=part)
+        # the input transform is kept for this convolution's weight gradient (same V: saves its recomputation there)
+        v = _wino_conv(d, x, w, k, c, False, bias, y, part=part)
+        if _wino["keep_v"]:
+            y._vspw_wino_v = v  # picked up (and removed) by the autograd node that called us
         return y, part, d
     if want_stats:
         tiles = _C.query("vspw_conv2d_stats_partials", ctypes.byref(d))
@@ -191,10 +195,7 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None)
     return y, part, d
 
 
-# [Cin][KH][KW][Cout] copies of the convolution weights for the data-gradient GEMMs.  Weights change once per step (the
-# optimizer), so the copies are refreshed once per step - ALL of them by one multi-tensor launch, triggered by the first
-# data gradient that finds its copy stale - instead of one 5 us launch per layer inside the backward critical path.
-_wt_cache = {"entries": {}, "order": [], "table": None, "table_n": 0, "tiles": 0, "gen": 0}
+_wt_cache = {"gen": 0}  # generation counter shared by every derived-weight cache (see invalidate_inference_cache)
 _WT_ENTRY = None
 
 
@@ -202,78 +203,131 @@ def _wt_key(w):
     return (w.data_ptr(), w._version, _wt_cache["gen"], tuple(w.shape))
 
 
-def _wt_upload_table(device):
-    import numpy as np
+class _DerivedWeights(object):
+    """Per-step cache of tensors derived from convolution weights (the [Cin][taps][Cout] copies of the data-gradient
+    GEMMs; the Winograd transforms).  Weights change once per step (the optimizer), so the derived tensors are
+    refreshed once per step - ALL of them by one multi-tensor launch over a device table (struct vspw_wt_entry),
+    triggered by the first use that finds its entry stale - instead of one small launch per layer inside the critical
+    path.  alloc(w) -> buffer; single(w, buf, stream); multi = C entry point taking (table, n, tiles, stream);
+    tiles(k, c, kh, kw) -> workgroups of one tensor in the multi launch."""
 
-    global _WT_ENTRY
-    if _WT_ENTRY is None:  # struct vspw_wt_entry (include/vspw_hip.h)
-        _WT_ENTRY = np.dtype([("w", "<u8"), ("wT", "<u8"), ("tile0", "<i8"), ("k", "<i4"), ("taps", "<i4"),
-                              ("c", "<i4"), ("reserved", "<i4")])
-    ents = [_wt_cache["entries"][i] for i in _wt_cache["order"]]
-    rec = np.zeros(len(ents), dtype=_WT_ENTRY)
-    t0 = 0
-    for i, e in enumerate(ents):
-        k, c, kh, kw = e["shape"]
-        rec[i] = (e["ptr"], e["wT"].data_ptr(), t0, k, kh * kw, c, 0)
-        t0 += int(_C.query("vspw_weight_transpose_tiles", k, kh * kw, c))
-    _wt_cache["table"] = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
-    _wt_cache["table_n"] = len(ents)
-    _wt_cache["tiles"] = t0
+    def __init__(self, alloc, single, multi, tiles):
+        self.alloc, self.single, self.multi, self.tiles = alloc, single, multi, tiles
+        self.clear()
+
+    def clear(self):
+        self.entries, self.order, self.table, self.table_n, self.total = {}, [], None, 0, 0
+
+    def _upload(self, device):
+        import numpy as np
+
+        global _WT_ENTRY
+        if _WT_ENTRY is None:  # struct vspw_wt_entry (include/vspw_hip.h)
+            _WT_ENTRY = np.dtype([("w", "<u8"), ("wT", "<u8"), ("tile0", "<i8"), ("k", "<i4"), ("taps", "<i4"),
+                                  ("c", "<i4"), ("reserved", "<i4")])
+        ents = [self.entries[i] for i in self.order]
+        rec = np.zeros(len(ents), dtype=_WT_ENTRY)
+        t0 = 0
+        for i, e in enumerate(ents):
+            k, c, kh, kw = e["shape"]
+            rec[i] = (e["ptr"], e["buf"].data_ptr(), t0, k, kh * kw, c, 0)
+            t0 += int(self.tiles(k, c, kh, kw))
+        self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
+        self.table_n = len(ents)
+        self.total = t0
+
+    def get(self, w):
+        import weakref
+
+        ents = self.entries
+        ident = (w.data_ptr(), tuple(w.shape))
+        e = ents.get(ident)
+        key = _wt_key(w)
+        if e is not None and e["ref"]() is None:
+            # the tensor this entry was made for is gone: its storage may have been freed and handed to ANOTHER weight
+            # with the same address / shape / version, so nothing cached under this identity can be trusted
+            del ents[ident]
+            self.order = [i for i in self.order if i != ident]
+            self.table = None
+            e = None
+        if e is not None and e["key"] == key:
+            return e["buf"]
+        capturing = torch.cuda.is_current_stream_capturing()
+        if e is None:
+            # first sight of this weight: own launch now, member of the batched refresh from the next step on
+            buf = self.alloc(w)
+            if capturing:  # a buffer from the graph's private pool must not leak into the eager cache
+                self.single(w, buf, _stream())
+                return buf
+            ents[ident] = e = {"buf": buf, "ptr": w.data_ptr(), "shape": tuple(w.shape), "key": None,
+                               "ref": weakref.ref(w)}
+            self.order.append(ident)
+            self.table = None
+        if not capturing:
+            dead = [i for i, x in ents.items() if x["ref"]() is None]
+            if dead:  # weights of a model that no longer exists
+                for i in dead:
+                    del ents[i]
+                self.order = [i for i in self.order if i in ents]
+                self.table = None
+            if self.table is None and len(ents) > 1 and all(
+                    x["key"] is None or x["key"][2] != _wt_cache["gen"] for x in ents.values()):
+                self._upload(w.device)
+        if self.table is not None and self.table_n == len(ents):
+            # refresh every registered tensor in one launch (they all went stale together: same optimizer step)
+            _C.call(self.multi, _p(self.table), self.table_n, self.total, _stream())
+            for x in ents.values():
+                t = x["ref"]()
+                x["key"] = _wt_key(t) if t is not None else None
+            e["key"] = key
+            return e["buf"]
+        self.single(w, e["buf"], _stream())
+        e["key"] = key
+        return e["buf"]
+
+
+def _wt_alloc(w):
+    k, c, kh, kw = w.shape
+    return torch.empty((c, kh, kw, k), device=w.device, dtype=torch.float32)
+
+
+def _wt_single(w, buf, st):
+    k, c, kh, kw = w.shape
+    _C.call("vspw_weight_transpose", _p(w), _p(buf), k, kh * kw, c, st)
+
+
+_wt_copies = _DerivedWeights(_wt_alloc, _wt_single, "vspw_weight_transpose_multi",
+                             lambda k, c, kh, kw: _C.query("vspw_weight_transpose_tiles", k, kh * kw, c))
 
 
 def _transposed_weight(w):
     """wT for the data gradient of a conv with weight w ([K][KH][KW][C] memory), from the per-step cache."""
-    import weakref
+    return _wt_copies.get(w)
 
-    ents = _wt_cache["entries"]
-    ident = (w.data_ptr(), tuple(w.shape))
-    e = ents.get(ident)
-    key = _wt_key(w)
-    if e is not None and e["ref"]() is None:
-        # the tensor this entry was made for is gone: its storage may have been freed and handed to ANOTHER weight with
-        # the same address / shape / version, so nothing cached under this identity can be trusted
-        del ents[ident]
-        _wt_cache["order"] = [i for i in _wt_cache["order"] if i != ident]
-        _wt_cache["table"] = None
-        e = None
-    if e is not None and e["key"] == key:
-        return e["wT"]
+
+def _wu_alloc(w):
     k, c, kh, kw = w.shape
-    capturing = torch.cuda.is_current_stream_capturing()
-    if e is None:
-        # first sight of this weight: own launch now, member of the batched refresh from the next step on
-        wT = torch.empty((c, kh, kw, k), device=w.device, dtype=torch.float32)
-        if capturing:  # a buffer from the graph's private pool must not leak into the eager cache
-            _C.call("vspw_weight_transpose", _p(w), _p(wT), k, kh * kw, c, _stream())
-            return wT
-        ents[ident] = e = {"wT": wT, "ptr": w.data_ptr(), "shape": tuple(w.shape), "key": None, "ref": weakref.ref(w)}
-        _wt_cache["order"].append(ident)
-        _wt_cache["table"] = None
-    if not capturing:
-        dead = [i for i, x in ents.items() if x["ref"]() is None]
-        if dead:  # weights of a model that no longer exists
-            for i in dead:
-                del ents[i]
-            _wt_cache["order"] = [i for i in _wt_cache["order"] if i in ents]
-            _wt_cache["table"] = None
-        if _wt_cache["table"] is None and len(ents) > 1 and all(
-                x["key"] is None or x["key"][2] != _wt_cache["gen"] for x in ents.values()):
-            _wt_upload_table(w.device)
-    if _wt_cache["table"] is not None and _wt_cache["table_n"] == len(ents):
-        # refresh every registered copy in one launch (they all went stale together: same optimizer step)
-        _C.call("vspw_weight_transpose_multi", _p(_wt_cache["table"]), _wt_cache["table_n"], _wt_cache["tiles"], _stream())
-        for x in ents.values():
-            t = x["ref"]()
-            x["key"] = _wt_key(t) if t is not None else None
-        e["key"] = key
-        return e["wT"]
-    _C.call("vspw_weight_transpose", _p(w), _p(e["wT"]), k, kh * kw, c, _stream())
-    e["key"] = key
-    return e["wT"]
+    return torch.empty((2, 16, k * c), device=w.device, dtype=torch.float32)
+
+
+def _wu_single(w, buf, st):
+    k, c, kh, kw = w.shape
+    _C.call("vspw_wino_weights", _p(w), _p(buf[0]), k, c, 0, st)
+    _C.call("vspw_wino_weights", _p(w), _p(buf[1]), k, c, 1, st)
+
+
+_wu_copies = _DerivedWeights(_wu_alloc, _wu_single, "vspw_wino_weights_multi",
+                             lambda k, c, kh, kw: _C.query("vspw_wino_weight_tiles", k, c))
+
+
+def _wino_weights(w, data_gradient):
+    """U [16][Cout][Cin] (forward) or U' [16][Cin][Cout] (data gradient) of a 3x3 weight, from the per-step cache."""
+    return _wu_copies.get(w)[1 if data_gradient else 0]
 
 
 def drop_weight_transpose_cache():
-    _wt_cache.update(entries={}, order=[], table=None, table_n=0, tiles=0)
+    _wt_copies.clear()
+    _wu_copies.clear()
 
 
 def conv2d_backward_data(dy, w, d, addend=None, bn_front=None, aff=None):
@@ -356,12 +410,14 @@ def join_side_streams():
         _wgrad_side["dirty"] = False
 
 
-def _wino_wgrad(dy, x, d, dw):
-    """dW of a stride-1 3x3 convolution in the Winograd domain (see winograd.hip): 4/9 of the direct multiplications."""
+def _wino_wgrad(dy, x, d, dw, v=None):
+    """dW of a stride-1 3x3 convolution in the Winograd domain (see winograd.hip): 4/9 of the direct multiplications.
+    v: the input transform kept by the forward pass (recomputed from x when absent)."""
     dev, st = dy.device, _stream()
     T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
-    v = torch.empty((16, T, d.c), device=dev, dtype=torch.float32)
-    _C.call("vspw_wino_input", ctypes.byref(d), _p(x), d.c, _p(v), st)
+    if v is None or tuple(v.shape) != (16, T, d.c):
+        v = torch.empty((16, T, d.c), device=dev, dtype=torch.float32)
+        _C.call("vspw_wino_input", ctypes.byref(d), _p(x), d.c, _p(v), st)
     dm = torch.empty((16, T, d.k), device=dev, dtype=torch.float32)
     _C.call("vspw_wino_dy", ctypes.byref(d), _p(dy), d.k, _p(dm), st)
     du = torch.empty((16, d.k, d.c), device=dev, dtype=torch.float32)
@@ -373,10 +429,10 @@ def _wino_wgrad(dy, x, d, dw):
     _wino["launches"] += 1
 
 
-def _wgrad_launch(dy, x, d, aff=None):
+def _wgrad_launch(dy, x, d, aff=None, wino_v=None):
     dw = torch.empty((d.k, d.kh, d.kw, d.c), device=dy.device, dtype=torch.float32).permute(0, 3, 1, 2)
     if aff is None and _wino["wgrad"] and _wino_ok(d):
-        _wino_wgrad(dy, x, d, dw)
+        _wino_wgrad(dy, x, d, dw, wino_v)
         return dw, None
     nbytes = _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d))
     ws = _ws(nbytes, dy.device) if nbytes else None
@@ -389,28 +445,28 @@ def _wgrad_launch(dy, x, d, aff=None):
     return dw, ws
 
 
-def conv2d_backward_weight(dy, x, d, aff=None):
-    """aff = (y, coef): see conv2d_backward_data."""
+def conv2d_backward_weight(dy, x, d, aff=None, wino_v=None):
+    """aff = (y, coef): see conv2d_backward_data.  wino_v: see _wino_wgrad."""
     if not _wgrad_side["enabled"] or _ktimer["on"]:
-        return _wgrad_launch(dy, x, d, aff)[0]
+        return _wgrad_launch(dy, x, d, aff, wino_v)[0]
     main = torch.cuda.current_stream()
     side = _wgrad_side["stream"]
     if side is None:
         side = _wgrad_side["stream"] = torch.cuda.Stream(device=dy.device)
     side.wait_stream(main)  # fork: dY (and X) are complete on the main stream
     with torch.cuda.stream(side):
-        dw, ws = _wgrad_launch(dy, x, d, aff)
+        dw, ws = _wgrad_launch(dy, x, d, aff, wino_v)
     # dY / X / the workspace were allocated on the main stream's pool: keep them alive until the join so that the
     # allocator cannot hand their memory to a later main-stream kernel while the side-stream GEMM still reads it
     # (dW itself must NOT be referenced here: with a second owner autograd's AccumulateGrad would clone it - a copy on
     # the main stream that races with the side-stream GEMM - instead of adopting the tensor as p.grad)
     if torch.cuda.is_current_stream_capturing():
-        _wgrad_side["keep"].append((dy, x, ws, aff))  # graph-private pool: nothing is recycled before the join anyway
+        _wgrad_side["keep"].append((dy, x, ws, aff, wino_v))  # graph-private pool: nothing is recycled before the join anyway
     else:
         # eager: tell the caching allocator that the side stream uses these blocks - each is recycled as soon as ITS
         # GEMM has finished, so saved activations and dY tensors are released progressively during backward (a list
         # held until the join kept the sum of all dY tensors + split-K workspaces of a backward pass alive)
-        for t in (dy, x, ws) + (tuple(aff) if aff is not None else ()):
+        for t in (dy, x, ws, wino_v) + (tuple(aff) if aff is not None else ()):
             if t is not None:
                 t.record_stream(side)
     if not _wgrad_side["dirty"]:
@@ -439,6 +495,8 @@ class Conv2dFn(torch.autograd.Function):
         y, _, d = conv2d_forward(x, w, bias, stride, pad, dil)
         ctx.d = d
         ctx.has_bias = bias is not None
+        ctx.wino_v = getattr(y, "_vspw_wino_v", None)
+        y._vspw_wino_v = None
         ctx.save_for_backward(x, w)
         return y
 
@@ -453,7 +511,8 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv2d_backward_data(dy, w, d)
         if ctx.needs_input_grad[1]:
-            dw = conv2d_backward_weight(dy, x, d)
+            dw = conv2d_backward_weight(dy, x, d, wino_v=ctx.wino_v)
+        ctx.wino_v = None
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(d.n * d.oh * d.ow, d.k, dy)
         return dx, dw, db, None, None, None
@@ -765,6 +824,8 @@ class ConvBNActFn(torch.autograd.Function):
             _C.call("vspw_bn_apply", _p(y), _p(scale), _p(shift), _p(residual), _p(mask), _p(z), rows, c, h * wd,
                     1 if relu else 0, st)
         ctx.d = d
+        ctx.wino_v = getattr(y, "_vspw_wino_v", None)
+        y._vspw_wino_v = None
         ctx.training = training
         ctx.relu = relu
         ctx.count = count
@@ -855,7 +916,8 @@ class ConvBNActFn(torch.autograd.Function):
                 front = (x, ctx.in_link)
             dx = conv2d_backward_data(dy, w, d, addend=dskip if ctx.skip_out else None, bn_front=front, aff=aff)
         if ctx.needs_input_grad[1]:
-            dw = conv2d_backward_weight(dy, x, d, aff=aff)
+            dw = conv2d_backward_weight(dy, x, d, aff=aff, wino_v=ctx.wino_v)
+        ctx.wino_v = None
         if ctx.has_cbias and ctx.needs_input_grad[2]:
             dcb = colsum(rows, c, dy)
         return (dx, dw, dcb, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None,

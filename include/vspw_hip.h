@@ -110,6 +110,21 @@ int vspw_conv2d_bwd_weight_aff(const vspw_conv_desc* d, const float* g, const fl
 /* 1 when both affine-operand gradients above accept the geometry (the caller otherwise applies the BatchNorm backward
  * with vspw_bn_bwd_apply and runs the plain gradients). */
 size_t vspw_conv2d_bwd_aff_supported(const vspw_conv_desc* d);
+/* [k][taps][c] -> [c][taps][k] */
+int vspw_weight_transpose(const float* w, float* wT, int k, int taps, int c, void* stream);
+/* The same transpose for many weight tensors in ONE launch.  `entries` is a DEVICE array sorted by tile0 (= the sum of
+ * vspw_weight_transpose_tiles() of all preceding entries); total_tiles = grid size. */
+typedef struct vspw_wt_entry {
+    const float* w; /* [k][taps][c] */
+    float* wT;      /* [c][taps][k] */
+    long long tile0;
+    int k, taps, c, reserved;
+} vspw_wt_entry;
+long long vspw_weight_transpose_tiles(int k, int taps, int c);
+int vspw_weight_transpose_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream);
+/* [n][c][hw] -> [n][hw][c]: the reference feeds NCHW images (train_clip2.py:45-47). */
+int vspw_nchw_to_nhwc(const float* in, float* out, int n, int c, long long hw, void* stream);
+
 /* ---------------------------------------------------------------- Winograd F(2x2,3x3) (winograd.hip) --- */
 /* Stride-1 3x3 convolutions (pad == dilation; reference models/resnet.py:63-64 after models/models.py:737-750, heads
  * models/clip_psp.py:29-35,74-79, models/clip_ocr.py:44-45) as 16 batched GEMMs with 4/9 of the direct multiplications:
@@ -125,6 +140,10 @@ size_t vspw_wino_supported(const vspw_conv_desc* d);
 long long vspw_wino_tiles(const vspw_conv_desc* d);
 size_t vspw_wino_stat_partials(const vspw_conv_desc* d);
 int vspw_wino_weights(const float* w, float* u, int k, int c, int data_gradient, void* stream);
+/* Both transforms of many weight tensors in ONE launch: entries (device array, sorted by tile0 = sum of
+ * vspw_wino_weight_tiles() of the preceding entries), entry.wT -> [2][16][k*c] (forward, then data gradient). */
+long long vspw_wino_weight_tiles(int k, int c);
+int vspw_wino_weights_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream);
 int vspw_wino_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream);
 int vspw_wino_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
                      const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
@@ -133,20 +152,6 @@ int vspw_wino_output(const vspw_conv_desc* d, const float* m, int channels, cons
  * [16][Cout][Cin] with V = vspw_wino_input(x); dW = vspw_wino_dw(dU) in the weight layout [Cout][3][3][Cin]. */
 int vspw_wino_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream);
 int vspw_wino_dw(const float* du, float* dw, int k, int c, void* stream);
-/* [k][taps][c] -> [c][taps][k] */
-int vspw_weight_transpose(const float* w, float* wT, int k, int taps, int c, void* stream);
-/* The same transpose for many weight tensors in ONE launch.  `entries` is a DEVICE array sorted by tile0 (= the sum of
- * vspw_weight_transpose_tiles() of all preceding entries); total_tiles = grid size. */
-typedef struct vspw_wt_entry {
-    const float* w; /* [k][taps][c] */
-    float* wT;      /* [c][taps][k] */
-    long long tile0;
-    int k, taps, c, reserved;
-} vspw_wt_entry;
-long long vspw_weight_transpose_tiles(int k, int taps, int c);
-int vspw_weight_transpose_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream);
-/* [n][c][hw] -> [n][hw][c]: the reference feeds NCHW images (train_clip2.py:45-47). */
-int vspw_nchw_to_nhwc(const float* in, float* out, int n, int c, long long hw, void* stream);
 
 /* ---------------------------------------------------------------- batch norm (bn.hip) ------------- */
 /* Replaces SynchronizedBatchNorm2d.forward = F.batch_norm (models/sync_batchnorm/batchnorm.py:68-98) and its

@@ -79,6 +79,15 @@ struct IgemmNT {
     // batched plain GEMM (vspw_bmm_nt): blockIdx.y = batch index, element strides of src / wt / dst between batches
     int batch;
     long long bs_src, bs_wt, bs_dst;
+    // start stagger (see launch_igemm_nt): the first stagger_n workgroups of the grid - the ones dispatched together at
+    // launch - sleep ((id / stagger_div) % stagger_mod) * stagger_unit x 8 128 cycles before their first load
+    int stagger_n, stagger_div, stagger_mod, stagger_unit;
+    // Winograd input operand (AFF 4, winograd.hip): the A matrix of batch xi = (a, b) is (B^T d B)[a][b] of the 4x4 input
+    // patch of tile m - four +-1-weighted pixels of src - evaluated while the operand is staged, so the transformed
+    // input V [16][T][c] is never written.  src = the NHWC image tensor (nb, h, w, lds), m = tiles, oh = tiles per image,
+    // ow = 1; wino_d = dilation (0: off), wino_th x wino_tw = tiles per dilation sub-grid.  The grid is x-only:
+    // 16 batches fastest, so that the 16 transforms of a tile's patch are read while it is L2-resident.
+    int wino_d, wino_th, wino_tw;
 #ifdef VSPW_NT_DBG
     int dbg;  // diagnostic builds only (tools/diag/nt_exposed.py): 1 = no epilogue memory traffic, 2 = no K loop
 #endif
@@ -372,13 +381,21 @@ template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, int AFF = 0
 __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAPS == 0) ? 4 : ((NBUF == 1 && !(AFF && WM * WN > 3)) ? 3 : 2)) void igemm_nt_v2_kernel(
     IgemmNT pin) {
     IgemmNT p = pin;
-    if (pin.batch > 1) {
+    if (AFF != 4 && pin.batch > 1) {
         p.src += (size_t)blockIdx.y * pin.bs_src;
         p.wt += (size_t)blockIdx.y * pin.bs_wt;
         p.dst += (size_t)blockIdx.y * pin.bs_dst;
     }
+    if (p.stagger_unit > 0) {
+        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
+        if (lin < p.stagger_n) {
+            const int ph = (lin / p.stagger_div) % p.stagger_mod;
+            for (int i = 0; i < ph * p.stagger_unit; ++i) __builtin_amdgcn_s_sleep(127);
+        }
+    }
     static_assert(TAPS == 0 || (NBUF == 1 && MODE != 2), "tap-inner order: single LDS buffer, non-pointwise");
     static_assert(!AFF || (MODE == 2 && NBUF == 1), "transformed A operand: pointwise, single LDS buffer");
+    static_assert(AFF != 4 || WM * WN <= 3, "Winograd operand: 4 staged float4 per row - the 96- / 64-row tiles only");
     // AFF 1: A = coef0*src + coef1*src2 + coef2 (BatchNorm-backward apply); AFF 2: A = relu(coef0*src + coef1 + src2);
     // AFF 3: A = relu(coef0*src + coef1) (no residual)
     // (BatchNorm-forward apply + residual + ReLU of the producing node), also stored to zout
@@ -400,7 +417,14 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
     const int l31 = lane & 31, lh = lane >> 5;
 
     const int tiles_n = (p.nout + TN - 1) / TN;
-    const int vb = xcd_remap(blockIdx.x, gridDim.x);
+    int vb = xcd_remap(blockIdx.x, gridDim.x);
+    int xi = 0;
+    if constexpr (AFF == 4) {  // batch index = the 4 low bits of the (remapped) workgroup id
+        xi = vb & 15;
+        vb >>= 4;
+        p.wt += (size_t)xi * pin.bs_wt;
+        p.dst += (size_t)xi * pin.bs_dst;
+    }
     const int tile_n = vb % tiles_n;
     const int tile_m = vb / tiles_n;
     const int m0 = tile_m * TM, n0 = tile_n * TN;
@@ -429,9 +453,9 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
         const_cast<char*>(reinterpret_cast<const char*>((AFF == 1 || AFF == 2) ? p.src2 + (size_t)img0 * p.h * p.w * p.lds : p.src)), 0,
         (int)(unsigned)(a_rem < (long long)NT_OOR ? a_rem : (long long)NT_OOR), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(AFF ? p.coef : p.wt), 0, 3 * p.kdim * 4, 0x00020000);
+        const_cast<float*>((AFF && AFF != 4) ? p.coef : p.wt), 0, 3 * p.kdim * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char*>(AFF >= 2 ? p.zout + (size_t)img0 * p.h * p.w * p.lds : p.dst), 0,
+        reinterpret_cast<char*>((AFF == 2 || AFF == 3) ? p.zout + (size_t)img0 * p.h * p.w * p.lds : p.dst), 0,
         (int)(unsigned)(a_rem < (long long)NT_OOR ? a_rem : (long long)NT_OOR), 0x00020000);
     // MODE 2 = pointwise at compile time (1x1, stride 1, no padding: source pixel == output pixel, every tap in the
     // image): no tap state, no in-image bits, no selects - the K loop is a plain GEMM loop
@@ -440,7 +464,40 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
 
     int a_base[RA], a_by[RA], a_bx[RA];
     unsigned a_voff[RA];    // byte offset (from src0) of this row's source pixel for the current tap, + lcol; NT_OOR = pad
-    if (pointwise) {
+    unsigned a_w4[AFF == 4 ? 4 : 1][RA];  // AFF 4: the four patch pixels (2 rows x 2 columns of B^T d B's [a][b] entry)
+    float w4c[4] = {0.f, 0.f, 0.f, 0.f};  //        and their +-1 coefficients (workgroup-uniform)
+    if constexpr (AFF == 4) {
+        // B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]]: row a has two non-zeros, at patch rows I0[a], I1[a]
+        const int a = xi >> 2, b = xi & 3;
+        const int ia0 = a == 0 ? 0 : 1, ia1 = a == 0 ? 2 : (a == 3 ? 3 : 2);
+        const int jb0 = b == 0 ? 0 : 1, jb1 = b == 0 ? 2 : (b == 3 ? 3 : 2);
+        const float sa0 = a == 2 ? -1.f : 1.f, sa1 = (a == 0 || a == 3) ? -1.f : 1.f;
+        const float sb0 = b == 2 ? -1.f : 1.f, sb1 = (b == 0 || b == 3) ? -1.f : 1.f;
+        w4c[0] = sa0 * sb0; w4c[1] = sa0 * sb1; w4c[2] = sa1 * sb0; w4c[3] = sa1 * sb1;
+        const int per = p.wino_th * p.wino_tw;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int t = min(m0 + lrow + 32 * i, p.m - 1);
+            const int img = t / ohw;
+            int r = t - img * ohw;
+            const int sg = r / per;
+            r -= sg * per;
+            const int sy = sg / p.wino_d, sx = sg - sy * p.wino_d;
+            const int ty = r / p.wino_tw, tx = r - ty * p.wino_tw;
+            const int gy0 = 2 * ty - 1 + ia0, gy1 = 2 * ty - 1 + ia1, gx0 = 2 * tx - 1 + jb0, gx1 = 2 * tx - 1 + jb1;
+            const int py0 = gy0 * p.wino_d + sy, py1 = gy1 * p.wino_d + sy;
+            const int px0 = gx0 * p.wino_d + sx, px1 = gx1 * p.wino_d + sx;
+            const bool oy0 = (gy0 >= 0) & (py0 < p.h), oy1 = (gy1 >= 0) & (py1 < p.h);
+            const bool ox0 = (gx0 >= 0) & (px0 < p.w), ox1 = (gx1 >= 0) & (px1 < p.w);
+            const int rb0 = ((img - img0) * p.h + py0) * p.w, rb1 = ((img - img0) * p.h + py1) * p.w;
+            a_w4[0][i] = (oy0 & ox0) ? (unsigned)((rb0 + px0) * p.lds + lcol) * 4u : NT_OOR;
+            a_w4[1][i] = (oy0 & ox1) ? (unsigned)((rb0 + px1) * p.lds + lcol) * 4u : NT_OOR;
+            a_w4[2][i] = (oy1 & ox0) ? (unsigned)((rb1 + px0) * p.lds + lcol) * 4u : NT_OOR;
+            a_w4[3][i] = (oy1 & ox1) ? (unsigned)((rb1 + px1) * p.lds + lcol) * 4u : NT_OOR;
+            a_voff[i] = 0;
+            a_base[i] = a_by[i] = a_bx[i] = 0;
+        }
+    } else if (pointwise) {
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int m = min(m0 + lrow + 32 * i, p.m - 1) - img0 * ohw;
@@ -508,14 +565,26 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
     };
     f32x4 ra[RA], rb[RB];
     f32x4 ra2[(AFF == 1 || AFF == 2) ? RA : 1], cf[3];
+    f32x4 rw[AFF == 4 ? 3 : 1][RA];  // AFF 4: patch pixels 1..3 (pixel 0 sits in ra)
     int kb_regs = 0;  // k base of the tile currently held in the staging registers (AFF 2: where its z goes)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     auto load_tile = [&]() {
         if (more) {
+            if constexpr (AFF == 4) {
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_w4[0][i], cb * 4, 0));
+#pragma unroll
+                    for (int q = 1; q < 4; ++q)
+                        rw[q - 1][i] =
+                            __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_w4[q][i], cb * 4, 0));
+                }
+            } else {
 #pragma unroll
             for (int i = 0; i < RA; ++i)
                 ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_a, a_voff[i], cb * 4, 0));
-            if (AFF) {
+            }
+            if (AFF && AFF != 4) {
                 if (AFF != 3) {
 #pragma unroll
                     for (int i = 0; i < RA; ++i)
@@ -537,7 +606,12 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
 #pragma unroll
             for (int i = 0; i < RA; ++i) ra[i] = cf[0] * ra[i] + (cf[1] * ra2[i] + cf[2]);
         }
-        if (AFF >= 2) {  // same expression tree as bn_apply_kernel: (y*scale + shift) [+ residual], then ReLU
+        if constexpr (AFF == 4) {  // (B^T d B)[a][b]: four pixels with +-1 coefficients
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                ra[i] = (w4c[0] * ra[i] + w4c[1] * rw[0][i]) + (w4c[2] * rw[1][i] + w4c[3] * rw[2][i]);
+        }
+        if (AFF == 2 || AFF == 3) {  // same expression tree as bn_apply_kernel: (y*scale + shift) [+ residual], then ReLU
 #pragma unroll
             for (int i = 0; i < RA; ++i) {
                 f32x4 v = ra[i] * cf[0] + cf[1];
@@ -961,6 +1035,16 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);                                                       \
         hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, 2, 1, 0, A>), dim3(tiles, p.batch), dim3(256), 0, st, p);              \
     }
+        if (p.wino_d > 0) {  // Winograd input operand: 16 batches folded into grid.x (fastest), 96- or 64-row tiles
+            if (cfg == 12) {
+                int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, 2, 1, 0, 4>), dim3(tiles * 16), dim3(256), 0, st, p);
+            } else {
+                int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, 2, 1, 0, 4>), dim3(tiles * 16), dim3(256), 0, st, p);
+            }
+            return;
+        }
         if (p.src2 != nullptr && p.zout != nullptr) {  // fused forward apply of the producing node (A operand + z)
             NT_AFF_LAUNCH(2)
             return;
@@ -1040,9 +1124,16 @@ static int nt_decide(const IgemmNT& p, bool& v2) {
     return cfg;
 }
 
-static int launch_igemm_nt(const IgemmNT& p, hipStream_t st) {
+static int launch_igemm_nt(const IgemmNT& pin, hipStream_t st) {
     bool v2;
+    IgemmNT p = pin;
     const int cfg = nt_decide(p, v2);
+    {   // experiment knobs: VSPW_STAGGER="unit,div,mod,n"
+        static const char* sg = getenv("VSPW_STAGGER");
+        if (sg) sscanf(sg, "%d,%d,%d,%d", &p.stagger_unit, &p.stagger_div, &p.stagger_mod, &p.stagger_n);
+        if (p.stagger_mod < 1) p.stagger_mod = 1;
+        if (p.stagger_div < 1) p.stagger_div = 1;
+    }
     if (v2) {
         const bool pw = p.kh * p.kw == 1 && p.stride == 1 && p.pad == 0 && p.padw == 0;
         if (pw)
@@ -1759,6 +1850,8 @@ static bool fill_fwd_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
     p.src2 = nullptr; p.coef = nullptr; p.zout = nullptr;
     p.batch = 1; p.bs_src = p.bs_wt = p.bs_dst = 0;
+    p.stagger_n = p.stagger_div = p.stagger_mod = p.stagger_unit = 0;
+    p.wino_d = p.wino_th = p.wino_tw = 0;
 #ifdef VSPW_NT_DBG
     p.dbg = getenv("VSPW_NT_DBG") ? atoi(getenv("VSPW_NT_DBG")) : 0;
 #endif
@@ -1900,6 +1993,8 @@ static bool fill_bwd_data_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
     p.src2 = nullptr; p.coef = nullptr; p.zout = nullptr;
     p.batch = 1; p.bs_src = p.bs_wt = p.bs_dst = 0;
+    p.stagger_n = p.stagger_div = p.stagger_mod = p.stagger_unit = 0;
+    p.wino_d = p.wino_th = p.wino_tw = 0;
 #ifdef VSPW_NT_DBG
     p.dbg = getenv("VSPW_NT_DBG") ? atoi(getenv("VSPW_NT_DBG")) : 0;
 #endif
@@ -2239,4 +2334,34 @@ extern "C" size_t vspw_conv2d_bwd_aff_supported(const vspw_conv_desc* d) {
     int tm, tn;
     wgrad_tile(d, tm, tn);
     return (tn_v2 && tm == 128 && P % BK == 0) ? 1 : 0;
+}
+
+// M[xi] = (B^T d B)[xi] . U[xi]^T for the 16 Winograd positions in one launch, the input transform evaluated while the A
+// operand is staged (IgemmNT::wino_d): src = x (forward) or dY (data gradient), NHWC with `channels` channels;
+// u [16][rows][channels]; m [16][T][rows].
+extern "C" int vspw_wino_gemm_fused(const vspw_conv_desc* d, const float* src, int channels, const float* u, int rows,
+                                    float* m, void* stream) {
+    if (!d || !src || !u || !m || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->dil < 1 || d->pad != d->dil ||
+        d->pad_w != d->dil || d->oh != d->h || d->ow != d->w || channels % BK != 0 || rows % 4 != 0)
+        return VSPW_EINVAL;
+    const int dl = d->dil;
+    const int th = ((d->h + dl - 1) / dl + 1) / 2, tw = ((d->w + dl - 1) / dl + 1) / 2;
+    const long long tpi = (long long)dl * dl * th * tw, T = tpi * d->n;
+    if (T > 0x3fffffffLL) return VSPW_EINVAL;
+    vspw_conv_desc g;
+    bmm_nt_desc(g, (int)T, rows, channels);
+    IgemmNT p;
+    if (!conv_geometry_ok(&g) || !fill_fwd_params(&g, p)) return VSPW_EINVAL;
+    p.src = src; p.wt = u; p.dst = m;
+    p.nb = d->n; p.h = d->h; p.w = d->w; p.oh = (int)tpi; p.ow = 1;
+    p.batch = 16;
+    p.bs_src = 0; p.bs_wt = (long long)rows * channels; p.bs_dst = T * rows;
+    p.wino_d = dl; p.wino_th = th; p.wino_tw = tw;
+    bool v2;
+    int cfg = nt_decide(p, v2);
+    if (!v2) return VSPW_EINVAL;
+    static const int force = getenv("VSPW_WINO_TILE") ? atoi(getenv("VSPW_WINO_TILE")) : 0;
+    cfg = force ? force : ((cfg == 11 || cfg == 12) ? 12 : 31);
+    launch_nt_v2<2>(p, cfg, vspw_stream(stream));
+    return vspw_launch_status();
 }

@@ -127,7 +127,12 @@ def _ws(nbytes, device):
 # implicit GEMM; VSPW_WINO_MINC = smallest channel count (both sides) that takes this path.
 _wino = {"enabled": os.environ.get("VSPW_WINOGRAD", "1") == "1", "min_c": int(os.environ.get("VSPW_WINO_MINC", "128")),
          "wgrad": os.environ.get("VSPW_WINO_WGRAD", "1") == "1", "launches": 0,
-         "keep_v": os.environ.get("VSPW_WINO_KEEP_V", "1") == "1"}
+         "keep_v": os.environ.get("VSPW_WINO_KEEP_V", "1") == "1",
+         # the GEMM evaluates the input transform itself (vspw_wino_gemm_fused); forward: off, its V is reused by the
+         # weight gradient
+         "fuse_fwd": os.environ.get("VSPW_WINO_FUSE_FWD", "0") == "1",
+         "fuse_dgrad": os.environ.get("VSPW_WINO_FUSE_DGRAD", "1") == "1",
+         "fuse_max_rows": int(os.environ.get("VSPW_WINO_FUSE_MAXROWS", "512"))}
 
 
 def set_winograd(enabled):
@@ -145,11 +150,20 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
     st = _stream()
     T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
     u = _wino_weights(w, data_gradient)
-    v = torch.empty((16, T, reduce_c), device=dev, dtype=torch.float32)
-    _C.call("vspw_wino_input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
     m = torch.empty((16, T, rows), device=dev, dtype=torch.float32)
-    with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-wino")):
-        _C.call("vspw_bmm_nt", _p(v), _p(u), _p(m), 16, T, rows, reduce_c, st)
+    v = None
+    # measured (bench shapes): staging the transform costs the GEMM ~10 % (4 loads + 16 VALU per staged float4 on the
+    # lanes fp32 MFMA shares), the separate transform pass costs time proportional to the INPUT only: fusing wins up
+    # to 512 output rows (256->256: -31 us per launch) and loses beyond (512->1024, 512->4096)
+    fused = (_wino["fuse_dgrad"] if data_gradient else _wino["fuse_fwd"]) and rows <= _wino["fuse_max_rows"]
+    if fused:  # the input transform is evaluated by the GEMM while it stages its A operand: V is never written
+        with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-winof")):
+            _C.call("vspw_wino_gemm_fused", ctypes.byref(d), _p(src), reduce_c, _p(u), rows, _p(m), st)
+    else:
+        v = torch.empty((16, T, reduce_c), device=dev, dtype=torch.float32)
+        _C.call("vspw_wino_input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
+        with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-wino")):
+            _C.call("vspw_bmm_nt", _p(v), _p(u), _p(m), 16, T, rows, reduce_c, st)
     z = y_ = mean = invstd = None
     if front is not None:
         z, y_, mean, invstd = front
@@ -179,7 +193,7 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None)
                                dtype=torch.float32)
         # the input transform is kept for this convolution's weight gradient (same V: saves its recomputation there)
         v = _wino_conv(d, x, w, k, c, False, bias, y, part=part)
-        if _wino["keep_v"]:
+        if _wino["keep_v"] and v is not None:
             y._vspw_wino_v = v  # picked up (and removed) by the autograd node that called us
         return y, part, d
     if want_stats:

@@ -145,6 +145,10 @@ int vspw_wino_weights(const float* w, float* u, int k, int c, int data_gradient,
 long long vspw_wino_weight_tiles(int k, int c);
 int vspw_wino_weights_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream);
 int vspw_wino_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream);
+/* vspw_wino_input + vspw_bmm_nt in one launch: the input transform is evaluated while the GEMM stages its A operand
+ * (V is never written).  src = x or dY (NHWC, `channels`), u [16][rows][channels], m [16][T][rows]. */
+int vspw_wino_gemm_fused(const vspw_conv_desc* d, const float* src, int channels, const float* u, int rows, float* m,
+                         void* stream);
 int vspw_wino_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
                      const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
                      float* stat_part, void* stream);

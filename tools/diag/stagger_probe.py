@@ -1,0 +1,22 @@
+"""Start-stagger experiment for short-K GEMMs: VSPW_STAGGER="unit,div,mod,n" (read once per process)."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+from cvpr2021_vspw_implement_amd import _C
+dev = torch.device("cuda:0")
+def timeit(fn, iters=40):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+out = []
+for name, B, M, N, K in (("wino256", 16, 9000, 256, 256), ("wino512d4", 16, 10240, 512, 512), ("pw256->1024", 1, 36000, 1024, 256), ("pw1024->256", 1, 36000, 256, 1024)):
+    a = torch.randn(B, M, K, device=dev); b = torch.randn(B, N, K, device=dev); c = torch.empty(B, M, N, device=dev)
+    us = timeit(lambda: _C.call("vspw_bmm_nt", a.data_ptr(), b.data_ptr(), c.data_ptr(), B, M, N, K, st))
+    out.append("%s %.1f us %.1f TF" % (name, us, 2.0 * B * M * N * K / us / 1e6))
+print("%-16s" % os.environ.get("VSPW_STAGGER", "none"), " | ".join(out))

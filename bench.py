@@ -51,11 +51,17 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-size", type=int, default=CROP,
                     help="crop of the CPU-baseline sample (B=2 clips x 1 frame); 479 = the workload's own frame size")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="time ONE complete B=2, T=5 step of the oracle instead of 1 of the 5 frames x5 (minutes)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-host-probe", action="store_true")
     ap.add_argument("--kernel-report", default="", help="write a per-shape GEMM efficiency table to this file "
                                                         "(every timed step runs eagerly with per-launch events)")
     ap.add_argument("--method", default="clip_psp", choices=["clip_psp", "clip_ocr"])
+    ap.add_argument("--no-sync-bn", action="store_true",
+                    help="N > 1: every rank normalises with its own batch statistics (no per-layer exchange)")
+    ap.add_argument("--sync-bn-clamp-var", action="store_true",
+                    help="N > 1: clamp(var, eps)^-1/2 as the reference's multi-device SyncBN (batchnorm.py:150)")
     return ap.parse_args()
 
 
@@ -118,11 +124,12 @@ def make_inputs(dev, seed, crop=CROP):
     return imgs, labs
 
 
-def cpu_baseline(S=CROP):
+def cpu_baseline(S=CROP, full=False):
     """Numpy-oracle port timed on the host cores: TCB-PSP R101 forward+backward on B=2 clips x 1 of the 5 frames at
     SxS (default: the workload's own 479x479 frames, no pixel extrapolation).  The encoder / deep-supervision cost is
-    linear in the number of frames, so one B=2, T=5 step = 5x this sample: clips/s = 2 / (5 t) (x (479/S)^2 if a
-    smaller S was asked for)."""
+    linear in the number of frames, so one B=2, T=5 step ~ 5x this sample: clips/s = 2 / (5 t) (x (479/S)^2 if a
+    smaller S was asked for); the x5 over-counts the pyramid head, which runs on the current frame only (4 % of the
+    step's FLOPs).  full=True times one complete T=5 step instead (--cpu-baseline-full; several minutes)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     from helpers import build, det_numpy_state
@@ -133,14 +140,15 @@ def cpu_baseline(S=CROP):
     O.set_dtype(np.float32)
     mod = build("clip_psp", "resnet101dilated")
     sd = det_numpy_state(mod)
-    imgs = [det_input("bench:0", (B_CLIPS, 3, S, S))]
-    labs = [det_labels("bench:0", (B_CLIPS, 1, S, S), K_CLASSES)]
+    nfr = T_FRAMES if full else 1
+    imgs = [det_input("bench:%d" % t, (B_CLIPS, 3, S, S)) for t in range(nfr)]
+    labs = [det_labels("bench:%d" % t, (B_CLIPS, 1, S, S), K_CLASSES) for t in range(nfr)]
     t0 = time.time()
     P = NM.Params(sd, train_params=True)
     loss, _ = NM.clip_psp(P, "resnet101", imgs, labs, True)
     O.tape().backward(loss)
     dt = time.time() - t0
-    scale = T_FRAMES * (CROP / float(S)) ** 2
+    scale = (T_FRAMES / float(nfr)) * (CROP / float(S)) ** 2
     cores = os.cpu_count() or 1
     try:  # threads the BLAS behind numpy.matmul actually used
         from threadpoolctl import threadpool_info
@@ -152,9 +160,10 @@ def cpu_baseline(S=CROP):
         pass
     return {"value": B_CLIPS / (dt * scale), "unit": "clips/s", "cores": cores, "host_cpus": os.cpu_count(),
             "kind": "port",
-            "sample": "numpy oracle (oracle/np_models.clip_psp, R101) fwd+bwd on B=2 clips x 1 frame at %dx%d: %.1f s "
-                      "on %d BLAS threads; x%.2f (5 frames%s) = one B=2,T=5,479^2 step"
-                      % (S, S, dt, cores, scale, "" if S == CROP else ", (479/%d)^2 pixels" % S),
+            "sample": "numpy oracle (oracle/np_models.clip_psp, R101) fwd+bwd on B=2 clips x %d frame(s) at %dx%d: %.1f s "
+                      "on %d BLAS threads; x%.2f (%s%s) = one B=2,T=5,479^2 step"
+                      % (nfr, S, S, dt, cores, scale, "all 5 frames timed" if full else "5 frames",
+                         "" if S == CROP else ", (479/%d)^2 pixels" % S),
             "reference_cpu_context": REFERENCE_CPU}
 
 
@@ -222,7 +231,8 @@ def main():
     # param broadcast, bucketed grad all-reduce, SyncBN over RCCL (N>1); VSPW_FORCE_COLLECTIVES=1 runs the same
     # collectives in a 1-rank RCCL group (the only way to exercise them on a single-GPU box)
     force = os.environ.get("VSPW_FORCE_COLLECTIVES") == "1"
-    model = vdist.DataParallelOverRCCL(net, force_collectives=force)
+    model = vdist.DataParallelOverRCCL(net, force_collectives=force, sync_bn=not args.no_sync_bn,
+                                       sync_bn_clamp_var=args.sync_bn_clamp_var)
     opt = optim.create_optimizers(net, lr=0.002, weight_decay=1e-4, momentum=0.9)
     imgs, labs = make_inputs(dev, 304 + rank)
     max_iters = 1000
@@ -251,10 +261,13 @@ def main():
     mode = args.mode
     if SHARED_GPU_TEST and collectives:
         mode = "eager"  # gloo collectives stage through the host: not capturable
+    rccl_capture = None  # None: not probed (no collectives / mode forced)
     if mode == "auto":
         mode = "graph"
-        if collectives and not rccl_capture_preflight(dev):
-            mode = "eager"
+        if collectives:
+            rccl_capture = rccl_capture_preflight(dev)
+            if not rccl_capture:
+                mode = "eager"
     graphed = None
     if mode == "graph":
         optim.adjust_learning_rate(opt, 0, max_iters, 0.002)
@@ -269,6 +282,8 @@ def main():
             flag = torch.tensor([1.0 if ok else 0.0], device=dev)
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
             ok = bool(flag.item() > 0.5)
+        if collectives:
+            rccl_capture = ok if rccl_capture in (None, True) else rccl_capture
         if not ok:
             graphed = None
 
@@ -296,15 +311,21 @@ def main():
         timed_steps = {0, args.steps // 2, args.steps - 1}
     ops.kernel_timer(False)
     ops.kernel_timer_reset()
+    bn_events, red_events = [], {}
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev = i in timed_steps
         ops.kernel_timer(ev, reset=False)
+        if collectives:  # HIP events around every collective of the eagerly issued (sampled) steps
+            ops.sync_bn_timer(bn_events if ev else None)
+            model.reducer.timer = red_events if ev else None
         loss = run_step(args.warmup + 1 + i, eager=ev)
     host_enqueue = time.perf_counter() - t0  # host time to enqueue all K steps (GPU still running)
     barrier()
     elapsed = time.perf_counter() - t0
     ops.kernel_timer(False, reset=False)
+    ops.sync_bn_timer(None)
+    model.reducer.timer = None
     last_loss = float(loss.item())
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -316,7 +337,7 @@ def main():
         allrecs = ops.kernel_timer_records()
         if args.kernel_report and rank == 0:
             agg = {}
-            for name, fl, ms, tag in allrecs:
+            for name, fl, ms, tag, _eff in allrecs:
                 a = agg.setdefault(tag, [0, 0.0, 0.0])
                 a[0] += 1
                 a[1] += fl
@@ -331,15 +352,37 @@ def main():
             flops = sum(r[1] for r in recs)
             ms = sum(r[2] for r in recs)
             achieved = flops / (ms * 1e-3) / 1e12
+            effective = sum(r[4] for r in recs) / (ms * 1e-3) / 1e12
             traffic, traffic_src = measured_traffic("igemm_nt_kernel")
             roofline = {"bound": "mfma", "kernel": "igemm_nt_kernel", "achieved": round(achieved, 2),
                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                        "what": "flops the launches EXECUTE (the Winograd F(2x2,3x3) GEMMs count their own 4/9 of the "
+                                "direct-convolution multiplications) / HIP-event time of those launches",
+                        "effective_direct_conv_tflops": round(effective, 2),
                         "traffic": traffic, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, %s)" % traffic_src,
                         "launches_per_step": len(recs) // max(len(timed_steps), 1),
                         "timed_steps": sorted(timed_steps),
                         "avg_launch_ms": round(ms / len(recs), 4),
                         "gflop_per_launch": round(flops / len(recs) / 1e9, 3),
                         "share_of_step_time": round(ms * 1e-3 / len(timed_steps) / (elapsed / args.steps), 3)}
+
+    # Multi-GPU diagnostics (also with VSPW_FORCE_COLLECTIVES=1 on one GPU): what the collectives of ONE eagerly issued
+    # step cost as seen from the compute stream.  syncbn_exchange = sum over the per-layer statistics all-reduces
+    # (forward + backward; each is on the critical path: the layer's normalisation waits for it); allreduce_exposed =
+    # time the stream spends in GradReducer.wait() (bucket all-reduces not hidden behind backward); allreduce_busy =
+    # sum over buckets of launch -> done.
+    comm = None
+    if collectives and timed_steps:
+        torch.cuda.synchronize()
+        nst = len(timed_steps)
+        comm = {"sampled_eager_steps": nst,
+                "syncbn_exchanges_per_step": len(bn_events) // nst,
+                "syncbn_exchange_ms_per_step": round(sum(a.elapsed_time(b) for a, b in bn_events) / nst, 3),
+                "grad_buckets": len(model.reducer.buckets),
+                "allreduce_exposed_ms_per_step": round(sum(a.elapsed_time(b) for a, b in red_events.get("wait", [])) / nst, 3),
+                "allreduce_busy_ms_per_step": round(sum(a.elapsed_time(b) for a, b in red_events.get("buckets", [])) / nst, 3),
+                "rccl_graph_capture": rccl_capture, "sync_bn": not args.no_sync_bn,
+                "sync_bn_formula": "clamp(var,eps)" if args.sync_bn_clamp_var else "var+eps"}
 
     # Host cost of ISSUING one eager step with GPU back-pressure excluded: the same launch sequence on 95x95 crops,
     # where the kernels take a few ms in total and the step time is the Python/ctypes/hipLaunch time itself.
@@ -382,20 +425,24 @@ def main():
                        if args.method == "clip_psp" else
                        "TCB-OCR (ClipOCRNet, resnet101dilated) train step: T=5, B=2/GPU, 479x479, 124 classes",
                        "global_batch_clips": world * B_CLIPS, "frames_per_step_per_gpu": T_FRAMES * B_CLIPS,
-                       "parallelism": "dp%d" % world, "sync_bn": collectives,
+                       "parallelism": "dp%d" % world, "sync_bn": collectives and not args.no_sync_bn,
                        "rccl_ranks": 0 if SHARED_GPU_TEST else (
                            torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
                        "execution": "hipGraph replay" if graphed is not None else "eager launches",
                        **({"backend": "gloo, ranks SHARING devices (VSPW_BENCH_SHARED_GPU test mode): plumbing check, "
                                       "not a measurement"} if SHARED_GPU_TEST else {})},
+            # direct-convolution FLOPs of the step (5785 GFLOP/clip) per second against the fp32 MFMA
+            # peak: an EFFECTIVE fraction - the Winograd path executes 4/9 of the multiplications of its 3x3 convs
             "e2e_mfma_frac": round(GFLOP_PER_CLIP * 1e9 * clips_per_s / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
             "last_loss": round(last_loss, 5),
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2),
             "host_probe": host_probe,
             "roofline": roofline,
         }
+        if comm is not None:
+            out["collectives"] = comm
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_size)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_size, full=args.cpu_baseline_full)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
     if rank == 0:

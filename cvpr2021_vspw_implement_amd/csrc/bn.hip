@@ -237,14 +237,16 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count
                                    const float* __restrict__ beta, float* __restrict__ rmean,
                                    float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
                                    float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift,
-                                   int c) {
+                                   int c, int clamp_var) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= c) return;
     double m = sums[i] / count;
     double var = sums[c + i] / count - m * m;
     if (var < 0) var = 0;
     float mf = (float)m;
-    float is = (float)(1.0 / sqrt(var + (double)eps));
+    // clamp_var: the reference's multi-device path, bias_var.clamp(eps) ** -0.5 (models/sync_batchnorm/batchnorm.py:150)
+    float is = clamp_var ? (float)(1.0 / sqrt(var > (double)eps ? var : (double)eps))
+                         : (float)(1.0 / sqrt(var + (double)eps));
     float g = gamma ? gamma[i] : 1.f;
     float b = beta ? beta[i] : 0.f;
     mean[i] = mf;
@@ -580,7 +582,16 @@ extern "C" int vspw_bn_finalize(const double* sums, double count, const float* g
                                 float* invstd, float* scale, float* shift, int c, void* stream) {
     if (!sums || !mean || !invstd || !scale || !shift || c <= 0 || !(count > 0)) return VSPW_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(vspw_cdiv(c, 256)), dim3(256), 0, vspw_stream(stream), sums, count,
-                       gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, c);
+                       gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, c, 0);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_bn_finalize_clamped(const double* sums, double count, const float* gamma, const float* beta,
+                                        float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                        float* invstd, float* scale, float* shift, int c, void* stream) {
+    if (!sums || !mean || !invstd || !scale || !shift || c <= 0 || !(count > 0)) return VSPW_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(vspw_cdiv(c, 256)), dim3(256), 0, vspw_stream(stream), sums, count,
+                       gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, c, 1);
     return vspw_launch_status();
 }
 

@@ -58,6 +58,7 @@ class GradReducer:
         so a parameter that got a gradient on ANY rank is updated on EVERY rank and one that got none anywhere keeps
         grad=None."""
         self.group = group
+        self.timer = None  # bench.py diagnostics: dict(buckets=[(launch event, done event)], wait=[(e0, e1)]) or None
         self.find_unused = bool(find_unused_parameters)
         self._flag_cache = {}
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -128,6 +129,10 @@ class GradReducer:
                 cached = (pattern, torch.tensor([1.0 if f else 0.0 for f in pattern]).to(self.flat[bi].device))
                 self._flag_cache[bi] = cached
             self.flat[bi][n:].copy_(cached[1])
+        if self.timer is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.timer.setdefault("launch", {})[bi] = e0
         self.handles[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
@@ -141,10 +146,17 @@ class GradReducer:
         if not self.active:
             return
         inv = 1.0 / self.world
+        if self.timer is not None:
+            w0 = torch.cuda.Event(enable_timing=True)
+            w0.record()
         for bi, bucket in enumerate(self.buckets):
             if self.pending[bi] != 0:  # parameters that got no gradient this step: reduce what is there
                 self._launch(bi)
             self.handles[bi].wait()
+            if self.timer is not None:
+                e1 = torch.cuda.Event(enable_timing=True)
+                e1.record()
+                self.timer.setdefault("buckets", []).append((self.timer["launch"].pop(bi), e1))
             self.flat[bi].mul_(inv)
             flags = None
             for j, p in enumerate(bucket):
@@ -164,19 +176,26 @@ class GradReducer:
                 p.grad = self.slots[id(p)]
             self.pending[bi] = len(bucket)
             self.handles[bi] = None
+        if self.timer is not None:
+            w1 = torch.cuda.Event(enable_timing=True)
+            w1.record()
+            self.timer.setdefault("wait", []).append((w0, w1))
 
 
 class DataParallelOverRCCL(torch.nn.Module):
     """Drop-in for `nn.DataParallel(module)` + `patch_replication_callback` in the clip drivers: same call
     signature (`module(feed_dict)` -> (loss, acc)), one process per GPU underneath."""
 
-    def __init__(self, module, bucket_mb=25.0, sync_bn=True, force_collectives=False, find_unused_parameters=False):
+    def __init__(self, module, bucket_mb=25.0, sync_bn=True, force_collectives=False, find_unused_parameters=False,
+                 sync_bn_clamp_var=False):
+        """sync_bn=False: every rank normalises with its own batch statistics (plain nn.BatchNorm under DDP).
+        sync_bn_clamp_var: see ops.set_sync_bn (the reference's multi-device clamp(var, eps) formula)."""
         super().__init__()
         self.module = module
         self.reducer = GradReducer(module, bucket_mb, force=force_collectives,
                                    find_unused_parameters=find_unused_parameters)
         self.reducer.broadcast_parameters(module)
-        ops.set_sync_bn(sync_bn and self.reducer.active, force=force_collectives)
+        ops.set_sync_bn(sync_bn and self.reducer.active, force=force_collectives, clamp_var=sync_bn_clamp_var)
 
     def forward(self, *a, **k):
         return self.module(*a, **k)

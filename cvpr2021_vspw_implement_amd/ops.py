@@ -86,14 +86,15 @@ def kernel_timer_reset():
 
 
 def kernel_timer_records():
-    """[(kernel name, algorithmic flops, ms)] for every timed launch (synchronises)."""
+    """[(kernel name, flops the launch executes, ms, tag, direct-convolution-equivalent flops)] for every timed launch
+    (synchronises).  The last two differ for the Winograd GEMMs only (4/9 of the direct multiplications)."""
     torch.cuda.synchronize()
-    return [(n, f, e0.elapsed_time(e1), tag) for n, f, e0, e1, tag in _ktimer["records"]]
+    return [(n, f, e0.elapsed_time(e1), tag, eff) for n, f, e0, e1, tag, eff in _ktimer["records"]]
 
 
 class _Timed:
-    def __init__(self, name, flops, tag=None):
-        self.name, self.flops, self.tag = name, flops, tag
+    def __init__(self, name, flops, tag=None, eff=None):
+        self.name, self.flops, self.tag, self.eff = name, flops, tag, (flops if eff is None else eff)
 
     def __enter__(self):
         if _ktimer["on"]:
@@ -105,7 +106,7 @@ class _Timed:
     def __exit__(self, *a):
         if _ktimer["on"]:
             self.e1.record()
-            _ktimer["records"].append((self.name, self.flops, self.e0, self.e1, self.tag))
+            _ktimer["records"].append((self.name, self.flops, self.e0, self.e1, self.tag, self.eff))
         return False
 
 
@@ -157,12 +158,12 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
     # to 512 output rows (256->256: -31 us per launch) and loses beyond (512->1024, 512->4096)
     fused = (_wino["fuse_dgrad"] if data_gradient else _wino["fuse_fwd"]) and rows <= _wino["fuse_max_rows"]
     if fused:  # the input transform is evaluated by the GEMM while it stages its A operand: V is never written
-        with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-winof")):
+        with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-winof"), _conv_flops(d)):
             _C.call("vspw_wino_gemm_fused", ctypes.byref(d), _p(src), reduce_c, _p(u), rows, _p(m), st)
     else:
         v = torch.empty((16, T, reduce_c), device=dev, dtype=torch.float32)
         _C.call("vspw_wino_input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
-        with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-wino")):
+        with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-wino"), _conv_flops(d)):
             _C.call("vspw_bmm_nt", _p(v), _p(u), _p(m), 16, T, rows, reduce_c, st)
     z = y_ = mean = invstd = None
     if front is not None:
@@ -437,7 +438,7 @@ def _wino_wgrad(dy, x, d, dw, v=None):
     du = torch.empty((16, d.k, d.c), device=dev, dtype=torch.float32)
     nbytes = _C.query("vspw_bmm_tn_workspace", 16, T, d.k, d.c)
     ws = _ws(nbytes, dev) if nbytes else None
-    with _Timed("igemm_tn_kernel", 2.0 * 16 * T * d.k * d.c, _conv_tag(d, "wgrad-wino")):
+    with _Timed("igemm_tn_kernel", 2.0 * 16 * T * d.k * d.c, _conv_tag(d, "wgrad-wino"), _conv_flops(d)):
         _C.call("vspw_bmm_tn", _p(dm), _p(v), _p(du), 16, T, d.k, d.c, _p(ws), nbytes, st)
     _C.call("vspw_wino_dw", _p(du), _p(dw), d.k, d.c, st)
     _wino["launches"] += 1
@@ -537,19 +538,29 @@ def conv2d(x, w, bias=None, stride=1, pad=0, dil=1):
 
 
 # --------------------------------------------------------------------------------------------------- batch norm
-_sync_group = {"enabled": False, "group": None, "force": False}
+_sync_group = {"enabled": False, "group": None, "force": False, "clamp_var": False, "timer": None}
 # populations up to this many rows take their statistics two-pass in fp64 from the activations (see bn.hip:
 # bn_small_finalize_kernel) instead of from the convolution epilogue's fp32 tile partials
 _BN_SMALL_ROWS = 1024
 
 
-def set_sync_bn(enabled, group=None, force=False):
+def set_sync_bn(enabled, group=None, force=False, clamp_var=False):
     """Enable the cross-rank exchange of BatchNorm statistics (SynchronizedBatchNorm semantics,
     models/sync_batchnorm/batchnorm.py:110-150) over torch.distributed (RCCL on ROCm).
-    `force` issues the collectives even in a 1-rank group (exercises the RCCL path on a single-GPU box)."""
+    `force` issues the collectives even in a 1-rank group (exercises the RCCL path on a single-GPU box).
+    clamp_var: invstd = clamp(var, eps)^-1/2 on the exchanged statistics - bit-for-bit the formula of the reference's
+    multi-device path (batchnorm.py:150); default False = (var + eps)^-1/2 everywhere, i.e. a multi-rank run computes
+    what ONE device would compute on the full batch (F.batch_norm; the numerics the oracle and the fixtures pin)."""
     _sync_group["enabled"] = bool(enabled)
     _sync_group["group"] = group
     _sync_group["force"] = bool(force)
+    _sync_group["clamp_var"] = bool(clamp_var)
+
+
+def sync_bn_timer(store):
+    """store = list: every statistics exchange appends (event before, event after) recorded on the launch stream
+    (bench.py's multi-GPU diagnostics); None switches it off."""
+    _sync_group["timer"] = store
 
 
 def _sync_world():
@@ -567,7 +578,18 @@ def _sync_world():
 def _all_reduce_sums(sums):
     import torch.distributed as dist
 
+    tm = _sync_group["timer"]
+    if tm is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_sync_group["group"])
+    if tm is not None:
+        e1.record()
+        tm.append((e0, e1))
+
+
+def _finalize_name():
+    return "vspw_bn_finalize_clamped" if _sync_group["clamp_var"] else "vspw_bn_finalize"
 
 
 # Decision tap (parity tests): ReLU and max-pool are the only non-smooth steps of the path.  When a list is installed
@@ -623,7 +645,8 @@ class BatchNormActFn(torch.autograd.Function):
                 if world != 1:
                     _all_reduce_sums(sums)
                     count = float(rows * max(world, 1))
-                _C.call("vspw_bn_finalize", _p(sums), ctypes.c_double(count), _p(gamma), _p(beta), _p(running_mean),
+                _C.call(_finalize_name() if world != 1 else "vspw_bn_finalize", _p(sums), ctypes.c_double(count),
+                        _p(gamma), _p(beta), _p(running_mean),
                         _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), c, st)
         else:
             _C.call("vspw_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(mean),
@@ -822,7 +845,8 @@ class ConvBNActFn(torch.autograd.Function):
                 if world != 1:
                     _all_reduce_sums(sums)
                     count = float(rows * max(world, 1))
-                _C.call("vspw_bn_finalize", _p(sums), ctypes.c_double(count), _p(gamma), _p(beta), _p(running_mean),
+                _C.call(_finalize_name() if world != 1 else "vspw_bn_finalize", _p(sums), ctypes.c_double(count),
+                        _p(gamma), _p(beta), _p(running_mean),
                         _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), c, st)
         else:
             _C.call("vspw_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(mean),

@@ -30,9 +30,10 @@ class SGD(torch.optim.Optimizer):
     parameter listed k times in a group is updated k times per step, the weight-decay term accumulating in the
     gradient across the k applications (1.3.1 adds it in place: d_p.add_(weight_decay, p.data)).
 
-    State layout differs from torch's in one way: group['params'] is de-duplicated and the multiplicities are kept in
-    group['mult'], so `opt_epoch_N.pth` files are NOT interchangeable with the reference's optimizer checkpoints
-    (model checkpoints are)."""
+    In memory group['params'] is de-duplicated (multiplicities in group['mult'], the original sequence in
+    group['order']); state_dict() / load_state_dict() speak torch.optim.Optimizer's own layout with the duplicates
+    expanded, i.e. `opt_epoch_N.pth` files are interchangeable with the reference's (train_clip2.py:179-189,347-357):
+    a run can be resumed from the reference's optimizer checkpoint and vice versa."""
 
     def __init__(self, params, lr=0.02, momentum=0.0, weight_decay=0.0):
         defaults = dict(lr=lr, momentum=momentum, weight_decay=weight_decay)
@@ -46,12 +47,62 @@ class SGD(torch.optim.Optimizer):
                 mult[p] = mult.get(p, 0) + 1
             g["params"] = list(mult.keys())
             g["mult"] = list(mult.values())
+            pos = {id(p): i for i, p in enumerate(g["params"])}
+            g["order"] = [pos[id(p)] for p in plist]  # the generator's sequence, duplicates included
             groups.append(g)
         super().__init__(groups, defaults)
         self._buckets = {}  # (momentum, device) -> {"key", "table", "pinned"}: one parameter table per launch
         self._lr_dev = None
         self._lr_host = None
         self._graph_keepalive = []
+
+    _PRIVATE = ("params", "mult", "order")
+
+    def state_dict(self):
+        """torch.optim.Optimizer.state_dict() of an SGD built on the ORIGINAL parameter lists (duplicates included):
+        parameters are numbered in listing order; a parameter repeated inside a group carries the index of its LAST
+        occurrence there (torch's dict-comprehension packing), one already seen in an earlier group keeps that group's
+        index; the counter advances over duplicates too; state is keyed by the packed index."""
+        mapping, start, groups = {}, 0, []
+        for g in self.param_groups:
+            expanded = [g["params"][i] for i in g["order"]]
+            mapping.update({id(p): i for i, p in enumerate(expanded, start) if id(p) not in mapping})
+            packed = {k: v for k, v in g.items() if k not in self._PRIVATE}
+            packed["params"] = [mapping[id(p)] for p in expanded]
+            start += len(expanded)
+            groups.append(packed)
+        state = {mapping[id(p)]: v for p, v in self.state.items() if id(p) in mapping}
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, state_dict):
+        """Accepts the layout above - what the reference's torch.optim.SGD wrote - and this class's round-2 layout
+        (de-duplicated lists with 'mult')."""
+        saved = state_dict["param_groups"]
+        if len(saved) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        if all("mult" in g for g in saved):
+            return super().load_state_dict(state_dict)
+        by_index = {}
+        for g, sg in zip(self.param_groups, saved):
+            expanded = [g["params"][i] for i in g["order"]]
+            if len(sg["params"]) != len(expanded):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of "
+                                 "optimizer's group")
+            for idx, p in zip(sg["params"], expanded):
+                if by_index.setdefault(idx, p) is not p:
+                    raise ValueError("loaded state dict maps index %d to two different parameters" % idx)
+            g.update({k: v for k, v in sg.items() if k not in self._PRIVATE})
+        self.state.clear()
+        for idx, st in state_dict["state"].items():
+            p = by_index[int(idx)]
+            new = {}
+            for k, v in st.items():
+                if torch.is_tensor(v) and v.shape == p.shape:
+                    # the fused kernel walks parameter, gradient and momentum in the parameter's element order
+                    v = torch.empty_like(p).copy_(v.to(device=p.device, dtype=p.dtype))
+                new[k] = v
+            self.state[p] = new
+        self._buckets = {}
 
     def _collect(self):
         """[(momentum, device) -> [(p, g, buf, lr_slot, wd, mult)]]; momentum buffers are created zero-filled, which

@@ -29,7 +29,7 @@ extern "C" {
 #define VSPW_EINVAL (-1)  /* bad argument / geometry / workspace too small */
 #define VSPW_ELAUNCH (-2) /* hipLaunchKernel reported an error */
 
-#define VSPW_ABI_VERSION 2
+#define VSPW_ABI_VERSION 3
 int vspw_abi_version(void);
 /* The hipError_t behind the most recent VSPW_ELAUNCH (0 if none) - for error messages. */
 int vspw_last_hip_error(void);
@@ -172,6 +172,11 @@ int vspw_bn_reduce_partials_f32(const float* part, int tiles, int c, double* sum
 int vspw_bn_finalize(const double* sums, double count, const float* gamma, const float* beta, float* running_mean,
                      float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                      float* shift, int c, void* stream);
+/* The same with invstd = clamp(var_biased, eps)^-1/2: what the reference's MULTI-device SynchronizedBatchNorm computes
+ * (models/sync_batchnorm/batchnorm.py:150); its single-device path is F.batch_norm's (var + eps)^-1/2. */
+int vspw_bn_finalize_clamped(const double* sums, double count, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                             float* shift, int c, void* stream);
 /* Populations of at most 1024 rows (pyramid-pool branches, OCR object contexts; reference models/clip_psp.py:45-56,
  * models/ocr_modules/spatial_ocr_block.py:247-289 through models/sync_batchnorm/batchnorm.py:70-73): statistics taken
  * from the activations two-pass in fp64 and finalised in the same launch (what ATen's CPU batch_norm does in its double

@@ -88,3 +88,43 @@ def test_eval_flags_and_palette():
     assert (a.batchsize, a.split, a.vc_clip_num, a.memory_num, a.clip_num) == (4, "val", 8, 8, 5) and a.use_memory
     assert E._palette[:9] == [0, 0, 0, 128, 0, 0, 0, 128, 0] and E._palette[27:30] == [191, 0, 0]
     assert E._palette[22 * 3:22 * 3 + 3] == [22, 22, 22] and len(E._palette) == 768
+
+
+def test_optimizer_checkpoint_layout_is_torchs_with_duplicates_expanded():
+    """opt_epoch_N.pth interchange (reference train_clip2.py:179-189,347-357): optim.SGD.state_dict() equals what
+    torch.optim.SGD - built, like the reference's, on parameter lists that repeat a parameter - writes: same index
+    lists, same state keys; and a torch-written state dict loads back into the de-duplicated optimizer."""
+    import warnings
+
+    import torch
+
+    from cvpr2021_vspw_implement_amd import optim
+
+    ps = [torch.nn.Parameter(torch.randn(3, 2, 1, 1)), torch.nn.Parameter(torch.randn(4)),
+          torch.nn.Parameter(torch.randn(2, 2))]
+    lists = [[ps[0], ps[1], ps[0]], [ps[2], ps[2], ps[2]]]
+    mk = lambda: [{"params": list(lists[0]), "lr": 0.1, "weight_decay": 1e-4},  # noqa: E731
+                  {"params": list(lists[1]), "lr": 0.01, "weight_decay": 0.0}]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = torch.optim.SGD(mk(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    for p in ps:
+        ref.state[p]["momentum_buffer"] = torch.randn_like(p)
+    want = ref.state_dict()
+    ours = optim.SGD(mk(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    assert [g["mult"] for g in ours.param_groups] == [[2, 1], [3]]
+    ours.load_state_dict(want)
+    got = ours.state_dict()
+    assert [g["params"] for g in got["param_groups"]] == [g["params"] for g in want["param_groups"]] == [[2, 1, 2], [5, 5, 5]]
+    assert set(got["state"]) == set(want["state"]) == {1, 2, 5}
+    for k in want["state"]:
+        assert torch.equal(got["state"][k]["momentum_buffer"], want["state"][k]["momentum_buffer"])
+    for g, w in zip(got["param_groups"], want["param_groups"]):
+        assert g["lr"] == w["lr"] and g["weight_decay"] == w["weight_decay"] and g["momentum"] == w["momentum"]
+        assert "mult" not in g and "order" not in g
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        back = torch.optim.SGD(mk(), lr=0.5, momentum=0.9)
+    back.load_state_dict(got)  # and torch reads what we write
+    assert back.param_groups[1]["lr"] == 0.01
+    assert torch.equal(back.state[ps[2]]["momentum_buffer"], ref.state[ps[2]]["momentum_buffer"])

@@ -9,7 +9,7 @@ VSPW_WGRAD_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT
 cd $GRAFT_REPO_ROOT
 python bench.py --no-cpu-baseline --no-host-probe --steps 6 --kernel-report $OUT/gemm_shapes.csv > $OUT/report.log 2>&1
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
-python tools/kernel_stats_summary.py $(find $OUT/trace_serial -name "*kernel_stats.csv" | head -1) $OUT/serial_kernel_stats.csv 5
-python tools/kernel_stats_summary.py $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 7
+python tools/kernel_stats_summary.py $(find $OUT/trace_serial -name "*kernel_stats.csv" | head -1) $OUT/serial_kernel_stats.csv
+python tools/kernel_stats_summary.py $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 du -sh $OUT; for f in $OUT/*.log; do grep "^{" $f | cut -c1-200; done
 head -40 $OUT/serial_kernel_stats.csv

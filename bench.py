@@ -13,8 +13,8 @@ is resident in HBM before the timed region; weights are random-init (no network 
 
 Execution mode (--mode): "graph" records the step once into a hipGraph and replays it (one hipGraphLaunch per step
 instead of ~1 400 Python-issued launches; cvpr2021_vspw_implement_amd/graph.py), "eager" issues every launch from
-Python, "auto" = graph when the step can be captured (always at N=1; at N>1 after a preflight that captures and
-replays one RCCL all-reduce), else eager.
+Python, "auto" = graph at N=1 and eager at N>1 (capturing RCCL collectives works but can abort the process through
+ProcessGroupNCCL's watchdog thread - see main(); `--mode graph` forces the captured path after a preflight).
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events recorded on the launch stream around every
 launch of the dominant kernel (igemm_nt_kernel: all convolution forward and data-gradient GEMMs, ~2/3 of the step's
@@ -182,7 +182,7 @@ def rccl_capture_preflight(dev):
         torch.cuda.synchronize()
         t.fill_(1.0)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):  # see graph.GraphedStep
             dist.all_reduce(t)
         g.replay()
         g.replay()
@@ -231,6 +231,13 @@ def main():
     # param broadcast, bucketed grad all-reduce, SyncBN over RCCL (N>1); VSPW_FORCE_COLLECTIVES=1 runs the same
     # collectives in a 1-rank RCCL group (the only way to exercise them on a single-GPU box)
     force = os.environ.get("VSPW_FORCE_COLLECTIVES") == "1"
+    work_stream = None
+    if world > 1 or force:
+        # one non-default stream for everything - hook registration, warm-up, capture, eagerly issued steps: the gradient
+        # hooks' AccumulateGrad nodes stay bound to the stream that is current when they are registered (graph.GraphedStep)
+        work_stream = torch.cuda.Stream()
+        work_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(work_stream)
     model = vdist.DataParallelOverRCCL(net, force_collectives=force, sync_bn=not args.no_sync_bn,
                                        sync_bn_clamp_var=args.sync_bn_clamp_var)
     opt = optim.create_optimizers(net, lr=0.002, weight_decay=1e-4, momentum=0.9)
@@ -261,19 +268,24 @@ def main():
     mode = args.mode
     if SHARED_GPU_TEST and collectives:
         mode = "eager"  # gloo collectives stage through the host: not capturable
-    rccl_capture = None  # None: not probed (no collectives / mode forced)
+    rccl_capture = None  # None: not attempted
     if mode == "auto":
-        mode = "graph"
-        if collectives:
-            rccl_capture = rccl_capture_preflight(dev)
-            if not rccl_capture:
-                mode = "eager"
+        # N = 1: one hipGraph replay per step.  With a process group alive (N > 1) `auto` issues the step EAGERLY:
+        # capturing it works (1-rank RCCL group on MI355X: 84-86 ms/step replayed, 93.6 ms eager) but in 3 runs of 6
+        # ProcessGroupNCCL's watchdog thread polled an event of a captured collective (hipErrorCapturedEvent), which
+        # invalidates the capture and aborts the PROCESS - not an exception this code could catch.  8 % is not worth a
+        # run that dies; `--mode graph` still takes the captured path (after the preflight below).
+        mode = "eager" if collectives else "graph"
+    if mode == "graph" and collectives:
+        rccl_capture = rccl_capture_preflight(dev)
+        if not rccl_capture:
+            mode = "eager"
     graphed = None
     if mode == "graph":
         optim.adjust_learning_rate(opt, 0, max_iters, 0.002)
         ok = True
         try:
-            graphed = GraphedStep(lambda: step_body(imgs, labs), warmup=2)
+            graphed = GraphedStep(lambda: step_body(imgs, labs), warmup=2, stream=work_stream)
         except Exception as e:  # noqa: BLE001 - e.g. a collective this RCCL build cannot record
             sys.stderr.write("rank %d: hipGraph capture of the step failed (%r); falling back to eager launches\n"
                              % (rank, e))
@@ -369,8 +381,9 @@ def main():
     # Multi-GPU diagnostics (also with VSPW_FORCE_COLLECTIVES=1 on one GPU): what the collectives of ONE eagerly issued
     # step cost as seen from the compute stream.  syncbn_exchange = sum over the per-layer statistics all-reduces
     # (forward + backward; each is on the critical path: the layer's normalisation waits for it); allreduce_exposed =
-    # time the stream spends in GradReducer.wait() (bucket all-reduces not hidden behind backward); allreduce_busy =
-    # sum over buckets of launch -> done.
+    # time the stream spends in GradReducer.wait() (bucket all-reduces not hidden behind backward);
+    # allreduce_launch_to_done_ms_max = the longest bucket's launch -> done interval (includes the backward work it
+    # overlapped with).
     comm = None
     if collectives and timed_steps:
         torch.cuda.synchronize()
@@ -380,7 +393,8 @@ def main():
                 "syncbn_exchange_ms_per_step": round(sum(a.elapsed_time(b) for a, b in bn_events) / nst, 3),
                 "grad_buckets": len(model.reducer.buckets),
                 "allreduce_exposed_ms_per_step": round(sum(a.elapsed_time(b) for a, b in red_events.get("wait", [])) / nst, 3),
-                "allreduce_busy_ms_per_step": round(sum(a.elapsed_time(b) for a, b in red_events.get("buckets", [])) / nst, 3),
+                "allreduce_launch_to_done_ms_max": round(max([a.elapsed_time(b) for a, b in red_events.get("buckets", [])]
+                                                            or [0.0]), 3),
                 "rccl_graph_capture": rccl_capture, "sync_bn": not args.no_sync_bn,
                 "sync_bn_formula": "clamp(var,eps)" if args.sync_bn_clamp_var else "var+eps"}
 

@@ -23,11 +23,18 @@ class GraphedStep(object):
     synchronisation (.item(), .cpu(), pageable copies) and must use only static input tensors; whatever it returns
     (tensors) stays valid and is overwritten by each replay."""
 
-    def __init__(self, fn, warmup=2):
+    def __init__(self, fn, warmup=2, stream=None):
+        """stream: capture on this (non-default) stream instead of a fresh one.  Needed when gradient hooks were
+        registered before the capture (distributed.GradReducer): register_post_accumulate_grad_hook creates the
+        AccumulateGrad nodes, which stay bound to the stream that was current THEN; if that is not the capturing stream
+        the hooks' collectives run outside the capture as far as ProcessGroupNCCL can tell, their work objects go to its
+        watchdog thread, and the watchdog aborts the process on the first captured event it polls
+        (hipErrorCapturedEvent - seen 3 runs of 4 with a 1-rank RCCL group).  bench.py / train_clip2 therefore make ONE
+        side stream current before they wrap the model and hand it in here."""
         if not torch.cuda.is_available():
             raise RuntimeError("GraphedStep needs a GPU (hipGraph capture)")
         self.fn = fn
-        side = torch.cuda.Stream()
+        side = stream if stream is not None else torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(int(warmup), 1)):
@@ -37,7 +44,10 @@ class GraphedStep(object):
         self.graph = torch.cuda.CUDAGraph()
         # capture on the stream the warm-up ran on: autograd's AccumulateGrad nodes remember the stream they were
         # created on, and a mismatch with the capturing stream would add cross-stream waits on a non-capturing stream
-        with torch.cuda.graph(self.graph, stream=side):
+        # capture_error_mode "thread_local": with a process group alive, ProcessGroupNCCL's watchdog THREAD polls its
+        # work events (hipEventQuery) at any time; under the default "global" mode that call is illegal while this
+        # thread captures, the watchdog throws and the process aborts (seen on MI355X with a 1-rank RCCL group).
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
             self.outputs = fn()
         self.stream = side
 

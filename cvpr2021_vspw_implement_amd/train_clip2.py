@@ -114,7 +114,7 @@ class GraphedTrainStep(object):
             return loss, acc
 
         try:
-            self.graph = GraphedStep(step, warmup=2)
+            self.graph = GraphedStep(step, warmup=2, stream=getattr(args, "_work_stream", None))
         finally:  # also when the capture fails (an RCCL build that cannot be captured): the warm-up steps are undone
             torch.cuda.synchronize()
             with torch.no_grad():
@@ -295,6 +295,10 @@ def main(cfg, gpus, args):
                                              map_location=device))
         log("resume from epoch {}".format(args.resume_epoch))
     if world > 1:
+        # one non-default stream for hook registration, training and (with --hip_graph) capture: see graph.GraphedStep
+        args._work_stream = torch.cuda.Stream(device)
+        args._work_stream.wait_stream(torch.cuda.current_stream(device))
+        torch.cuda.set_stream(args._work_stream)
         segmentation_module = vdist.DataParallelOverRCCL(segmentation_module)
 
     history = {"train": {"epoch": [], "loss": [], "acc": []}}

@@ -194,7 +194,9 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                                                           const float* __restrict__ bn_y,
                                                           const float* __restrict__ bn_mean,
                                                           const float* __restrict__ bn_invstd,
-                                                          float* __restrict__ stat_part, WinoGeom g, int K, int cl4) {
+                                                          float* __restrict__ stat_part,
+                                                          const float* __restrict__ addend, int act, WinoGeom g, int K,
+                                                          int cl4) {
     __shared__ f32x4 red[2][256];
     const int tid = threadIdx.x;
     const int lane_c = tid % cl4, lane_t = tid / cl4;
@@ -243,9 +245,16 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                     for (int c = 0; c < 4; ++c) o[c] = z[c] > 0.f ? o[c] : 0.f;
                     q4 += o * ((yv - mu) * is);
                     s4 += o;
-                } else if (stat_part != nullptr) {
-                    q4 += o * o;
-                    s4 += o;
+                } else {
+                    if (addend != nullptr) o += *reinterpret_cast<const f32x4*>(addend + e);  // inference: residual
+                    if (act == 1) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], 0.f);
+                    }
+                    if (stat_part != nullptr) {
+                        q4 += o * o;
+                        s4 += o;
+                    }
                 }
                 *reinterpret_cast<f32x4*>(y + e) = o;
             }
@@ -383,19 +392,21 @@ extern "C" int vspw_wino_input(const vspw_conv_desc* d, const float* x, int chan
 
 extern "C" int vspw_wino_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
                                 const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
-                                float* stat_part, void* stream) {
+                                float* stat_part, const float* addend, int act, void* stream) {
     WinoGeom g;
     const int cl4 = wino_cl4(channels);
+    if (act != 0 && act != 1) return VSPW_EINVAL;
+    if (relu_src != nullptr && (addend != nullptr || act != 0)) return VSPW_EINVAL;
     if (!wino_geom(d, g) || !m || !y || cl4 == 0) return VSPW_EINVAL;
     const bool front = relu_src != nullptr;
     if (front && (!bn_y || !bn_mean || !bn_invstd || !stat_part)) return VSPW_EINVAL;
     const dim3 grid(vspw_cdiv(g.T, WINO_TB), channels / 4 / cl4);
     if (front)
         hipLaunchKernelGGL(wino_output_kernel<true>, grid, dim3(256), 0, vspw_stream(stream), m, bias, y, relu_src, bn_y,
-                           bn_mean, bn_invstd, stat_part, g, channels, cl4);
+                           bn_mean, bn_invstd, stat_part, nullptr, 0, g, channels, cl4);
     else
         hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(256), 0, vspw_stream(stream), m, bias, y, nullptr, nullptr,
-                           nullptr, nullptr, stat_part, g, channels, cl4);
+                           nullptr, nullptr, stat_part, addend, act, g, channels, cl4);
     return vspw_launch_status();
 }
 

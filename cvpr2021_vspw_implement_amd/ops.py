@@ -145,18 +145,23 @@ def _wino_ok(d):
             and _C.query("vspw_wino_supported", ctypes.byref(d)) == 1)
 
 
-def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, part=None, what="fwd"):
-    """dst = conv(src) through U, V, M (see winograd.hip); rows = output channels, reduce_c = channels of src."""
+def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, part=None, what="fwd", u=None,
+               addend=None, act=0, fuse=None):
+    """dst = conv(src) through U, V, M (see winograd.hip); rows = output channels, reduce_c = channels of src.
+    u: transformed weights supplied by the caller (inference: of the BatchNorm-folded weights)."""
     dev = src.device
     st = _stream()
     T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
-    u = _wino_weights(w, data_gradient)
+    if u is None:
+        u = _wino_weights(w, data_gradient)
     m = torch.empty((16, T, rows), device=dev, dtype=torch.float32)
     v = None
     # measured (bench shapes): staging the transform costs the GEMM ~10 % (4 loads + 16 VALU per staged float4 on the
     # lanes fp32 MFMA shares), the separate transform pass costs time proportional to the INPUT only: fusing wins up
     # to 512 output rows (256->256: -31 us per launch) and loses beyond (512->1024, 512->4096)
-    fused = (_wino["fuse_dgrad"] if data_gradient else _wino["fuse_fwd"]) and rows <= _wino["fuse_max_rows"]
+    if fuse is None:
+        fuse = _wino["fuse_dgrad"] if data_gradient else _wino["fuse_fwd"]
+    fused = fuse and rows <= _wino["fuse_max_rows"]
     if fused:  # the input transform is evaluated by the GEMM while it stages its A operand: V is never written
         with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-winof"), _conv_flops(d)):
             _C.call("vspw_wino_gemm_fused", ctypes.byref(d), _p(src), reduce_c, _p(u), rows, _p(m), st)
@@ -169,7 +174,7 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
     if front is not None:
         z, y_, mean, invstd = front
     _C.call("vspw_wino_output", ctypes.byref(d), _p(m), rows, _p(bias), _p(dst), _p(z), _p(y_), _p(mean), _p(invstd),
-            _p(part), st)
+            _p(part), _p(addend), act, st)
     _wino["launches"] += 1
     return v
 
@@ -738,15 +743,22 @@ def _conv_bn_folded(x, w, cbias, gamma, beta, running_mean, running_var, residua
         wf = torch.empty((k, kh, kw, c), device=x.device, dtype=torch.float32)
         bf = torch.empty(k, device=x.device, dtype=torch.float32)
         _C.call("vspw_bn_fold_weights", _p(w), _p(cbias), _p(coef[2]), _p(coef[3]), _p(wf), _p(bf), k, kh * kw * c, st)
-        ent = (key, wf, bf)
+        ent = [key, wf, bf, None]
         _infer_fold["cache"][id(w)] = ent
-    _, wf, bf = ent
+    _, wf, bf = ent[0], ent[1], ent[2]
     d = _conv_desc(x, k, kh, kw, stride, pad, dil)
     z = empty_nhwc(d.n, k, d.oh, d.ow, x.device)
     if residual is not None:
         residual = to_nhwc(residual)
         if tuple(residual.shape) != tuple(z.shape):
             raise RuntimeError("conv_bn_act: residual %s vs output %s" % (tuple(residual.shape), tuple(z.shape)))
+    if _wino_ok(d):  # stride-1 3x3: Winograd on the folded weights (their transform is cached with them)
+        if ent[3] is None:
+            ent[3] = torch.empty((16, k, c), device=x.device, dtype=torch.float32)
+            _C.call("vspw_wino_weights", _p(wf), _p(ent[3]), k, c, 0, st)
+        _wino_conv(d, x, None, k, c, False, bf, z, what="fwd-fold", u=ent[3], addend=residual, act=1 if relu else 0,
+                   fuse=_wino["fuse_dgrad"])  # no weight gradient will want V: let the GEMM stage the transform
+        return z
     with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "fwd")):
         _C.call("vspw_conv2d_fwd_ex", ctypes.byref(d), _p(x), c, _p(wf), _p(bf), _p(residual), 1 if relu else 0, _p(z),
                 k, st)

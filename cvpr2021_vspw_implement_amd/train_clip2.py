@@ -294,6 +294,10 @@ def main(cfg, gpus, args):
         optimizer.load_state_dict(torch.load(os.path.join("./resume", "opt_epoch_{}.pth".format(args.resume_epoch)),
                                              map_location=device))
         log("resume from epoch {}".format(args.resume_epoch))
+    if world > 1 and getattr(args, "hip_graph", False) and os.environ.get("VSPW_GRAPH_WITH_COLLECTIVES") != "1":
+        # capturing RCCL collectives can abort the process through ProcessGroupNCCL's watchdog thread (bench.py main())
+        log("--hip_graph is ignored with %d ranks (set VSPW_GRAPH_WITH_COLLECTIVES=1 to capture anyway)" % world)
+        args.hip_graph = False
     if world > 1:
         # one non-default stream for hook registration, training and (with --hip_graph) capture: see graph.GraphedStep
         args._work_stream = torch.cuda.Stream(device)

@@ -135,7 +135,9 @@ int vspw_nchw_to_nhwc(const float* in, float* out, int n, int c, long long hw, v
  *   M = vspw_bmm_nt(V, U, batch 16)     [16][T][rows]
  *   y = vspw_wino_output(M)             NHWC, + bias; with stat_part: per-workgroup [2][channels] partial sums for the
  *       BatchNorm that follows (vspw_wino_stat_partials(d) rows); with relu_src/bn_*: the BatchNorm-backward front end
- *       of vspw_conv2d_bwd_data_bn.  `d` is the convolution's descriptor in every call (h, w, dil are used). */
+ *       of vspw_conv2d_bwd_data_bn; addend / act (0 none, 1 ReLU): the residual add and activation of the inference
+ *       path's folded conv + BatchNorm (vspw_conv2d_fwd_ex).  `d` is the convolution's descriptor in every call
+ *       (h, w, dil are used). */
 size_t vspw_wino_supported(const vspw_conv_desc* d);
 long long vspw_wino_tiles(const vspw_conv_desc* d);
 size_t vspw_wino_stat_partials(const vspw_conv_desc* d);
@@ -151,7 +153,7 @@ int vspw_wino_gemm_fused(const vspw_conv_desc* d, const float* src, int channels
                          void* stream);
 int vspw_wino_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
                      const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
-                     float* stat_part, void* stream);
+                     float* stat_part, const float* addend, int act, void* stream);
 /* Weight gradient in the transform domain: dM = vspw_wino_dy(dY) [16][T][Cout]; dU = vspw_bmm_tn(dM, V, batch 16)
  * [16][Cout][Cin] with V = vspw_wino_input(x); dW = vspw_wino_dw(dU) in the weight layout [Cout][3][3][Cin]. */
 int vspw_wino_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream);

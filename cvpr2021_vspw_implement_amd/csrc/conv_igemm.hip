@@ -31,7 +31,7 @@
 // DIAGNOSTIC build (-DVSPW_NT_TIMING): per-workgroup s_memtime stamps [start, after prologue, after K loop, end] + CU id
 // (-DVSPW_NT_TIMING=2: slot 1 is overwritten with "every store of the tile issued"); read by tools/diag/nt_phase.py
 __device__ unsigned long long vspw_nt_stamps[8192 * 5];
-#define NT_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 8192) vspw_nt_stamps[blockIdx.x * 5 + (i)] = __builtin_readcyclecounter()
+#define NT_STAMP(i) if (threadIdx.x == 0 && stamp_slot < 8192) vspw_nt_stamps[stamp_slot * 5 + (i)] = __builtin_readcyclecounter()
 #define TN_STAMP(i)                                                                       \
     if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 8192)                   \
     vspw_nt_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 5 + (i)] = __builtin_readcyclecounter()
@@ -79,9 +79,6 @@ struct IgemmNT {
     // batched plain GEMM (vspw_bmm_nt): blockIdx.y = batch index, element strides of src / wt / dst between batches
     int batch;
     long long bs_src, bs_wt, bs_dst;
-    // start stagger (see launch_igemm_nt): the first stagger_n workgroups of the grid - the ones dispatched together at
-    // launch - sleep ((id / stagger_div) % stagger_mod) * stagger_unit x 8 128 cycles before their first load
-    int stagger_n, stagger_div, stagger_mod, stagger_unit;
     // Winograd input operand (AFF 4, winograd.hip): the A matrix of batch xi = (a, b) is (B^T d B)[a][b] of the 4x4 input
     // patch of tile m - four +-1-weighted pixels of src - evaluated while the operand is staged, so the transformed
     // input V [16][T][c] is never written.  src = the NHWC image tensor (nb, h, w, lds), m = tiles, oh = tiles per image,
@@ -377,22 +374,21 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT pin) {
 #endif
 #define NT_PRIO(x) __builtin_amdgcn_s_setprio(x)
 
-template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, int AFF = 0>
-__global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAPS == 0) ? 4 : ((NBUF == 1 && !(AFF && WM * WN > 3)) ? 3 : 2)) void igemm_nt_v2_kernel(
-    IgemmNT pin) {
+#define NT_V2_BOUNDS(WM, WN, MODE, NBUF, TAPS, AFF) \
+    ((WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAPS == 0) ? 4 : ((NBUF == 1 && !(AFF && WM * WN > 3)) ? 3 : 2))
+
+// One output tile.  vb_in = tile index of this workgroup (already XCD-remapped), batch_idx = batch of a batched GEMM,
+// stamp_slot = slot of the diagnostic stamps.  Called once per workgroup by igemm_nt_v2_kernel and in a loop by the
+// persistent variant below.
+template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS, int AFF>
+__device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, int batch_idx, int stamp_slot) {
     IgemmNT p = pin;
     if (AFF != 4 && pin.batch > 1) {
-        p.src += (size_t)blockIdx.y * pin.bs_src;
-        p.wt += (size_t)blockIdx.y * pin.bs_wt;
-        p.dst += (size_t)blockIdx.y * pin.bs_dst;
+        p.src += (size_t)batch_idx * pin.bs_src;
+        p.wt += (size_t)batch_idx * pin.bs_wt;
+        p.dst += (size_t)batch_idx * pin.bs_dst;
     }
-    if (p.stagger_unit > 0) {
-        const int lin = blockIdx.y * gridDim.x + blockIdx.x;
-        if (lin < p.stagger_n) {
-            const int ph = (lin / p.stagger_div) % p.stagger_mod;
-            for (int i = 0; i < ph * p.stagger_unit; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
+    (void)stamp_slot;
     static_assert(TAPS == 0 || (NBUF == 1 && MODE != 2), "tap-inner order: single LDS buffer, non-pointwise");
     static_assert(!AFF || (MODE == 2 && NBUF == 1), "transformed A operand: pointwise, single LDS buffer");
     static_assert(AFF != 4 || WM * WN <= 3, "Winograd operand: 4 staged float4 per row - the 96- / 64-row tiles only");
@@ -417,7 +413,7 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
     const int l31 = lane & 31, lh = lane >> 5;
 
     const int tiles_n = (p.nout + TN - 1) / TN;
-    int vb = xcd_remap(blockIdx.x, gridDim.x);
+    int vb = vb_in;
     int xi = 0;
     if constexpr (AFF == 4) {  // batch index = the 4 low bits of the (remapped) workgroup id
         xi = vb & 15;
@@ -966,14 +962,43 @@ __global__ __launch_bounds__(256, (WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAP
 #ifdef VSPW_NT_TIMING
     __builtin_amdgcn_s_waitcnt(0);  // the diagnostic stamp counts the stores as drained; production waves just end
     NT_STAMP(3);
-    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    if (threadIdx.x == 0 && stamp_slot < 8192) {
         unsigned id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        vspw_nt_stamps[blockIdx.x * 5 + 4] = ((unsigned long long)xcc << 32) | id;
+        vspw_nt_stamps[stamp_slot * 5 + 4] = ((unsigned long long)xcc << 32) | id;
     }
 #endif
+}
+
+template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, int AFF = 0>
+__global__ __launch_bounds__(256, NT_V2_BOUNDS(WM, WN, MODE, NBUF, TAPS, AFF)) void igemm_nt_v2_kernel(IgemmNT pin) {
+    igemm_nt_v2_body<WGM, WM, WN, MODE, NBUF, TAPS, AFF>(pin, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y,
+                                                         blockIdx.y * gridDim.x + blockIdx.x);
+}
+
+// Persistent variant (short-K pointwise GEMMs): gridDim.x = resident workgroup slots (a multiple of 8), each workgroup
+// walks the tiles of its XCD's contiguous range with stride slots / 8.  Measured with per-workgroup stamps on the
+// Winograd 16 x 9000 x 256 x 256 GEMM (tools/diag/nt_occupancy.py): a workgroup lives 90 k cycles and its CU slot then
+// stays EMPTY for 2-10 k cycles until the dispatcher has placed the successor (37 KB LDS, 4 x 166 registers) - average
+// residency 2.6 of 3 workgroups per CU.  A workgroup that fetches its next tile itself has no such gap - but see
+// launch_nt_persist: it did not pay (experiment, VSPW_PERSIST=1).
+template <int WGM, int WM, int WN, int AFF>
+__global__ __launch_bounds__(256, NT_V2_BOUNDS(WM, WN, 2, 1, 0, AFF)) void igemm_nt_v2_persist_kernel(IgemmNT pin, int total,
+                                                                                                    int per_batch) {
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, nq = gridDim.x >> 3;
+    const int per = total >> 3, rem = total & 7;
+    const int base = (xcd < rem) ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per;
+    const int cnt = per + (xcd < rem ? 1 : 0);
+    for (int j = q; j < cnt; j += nq) {
+        const int lin = base + j;
+        if (AFF == 4)
+            igemm_nt_v2_body<WGM, WM, WN, 2, 1, 0, AFF>(pin, lin, 0, lin);
+        else
+            igemm_nt_v2_body<WGM, WM, WN, 2, 1, 0, AFF>(pin, lin % per_batch, lin / per_batch, lin);
+        __syncthreads();  // the next tile's operand stores must not overtake this tile's last LDS reads
+    }
 }
 
 #ifdef VSPW_NT_TIMING
@@ -1015,6 +1040,32 @@ static int nt_pick_tile(long long m, int nout, int batch = 1) {
 
 static int nt_tile_rows(int cfg) { return (cfg == 22 || cfg == 21) ? 128 : (cfg == 31 ? 96 : 64); }
 
+// Persistent launch of a pointwise GEMM (igemm_nt_v2_persist_kernel): grid = the workgroup slots of the chip.
+template <int WGM, int WM, int WN, int AFF>
+static bool launch_nt_persist(const IgemmNT& p, int tm, int tn, int fold, hipStream_t st) {
+    // OFF by default: measured (tools/diag/gemm_time.py, bench step) the walk gains nothing - Winograd 256 GEMM 193.6 ->
+    // 191.8 us, pointwise 256 -> 1024 149 -> 154 us, 512 -> 2048 547 -> 569 us, step 84.6 -> 86.5 ms: the static tile
+    // assignment loses to the dispatcher's dynamic one what the missing gaps win, and the loop costs 14-80 SGPR spills
+    static const int enabled = getenv("VSPW_PERSIST") ? atoi(getenv("VSPW_PERSIST")) : 0;
+    static const int max_k = getenv("VSPW_PERSIST_MAXK") ? atoi(getenv("VSPW_PERSIST_MAXK")) : 1024;
+    if (!enabled || p.kdim > max_k) return false;
+    static int slots = 0;
+    if (slots == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, igemm_nt_v2_persist_kernel<WGM, WM, WN, AFF>, 256, 0) !=
+                hipSuccess || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            per_cu = 0;
+        slots = per_cu > 0 ? (per_cu * prop.multiProcessorCount) / 8 * 8 : -1;
+    }
+    const int per_batch = vspw_cdiv(p.m, tm) * vspw_cdiv(p.nout, tn);
+    const long long total = (long long)per_batch * fold;
+    if (slots <= 0 || total <= slots || total > 0x7fffffffLL) return false;  // fewer tiles than slots: nothing to walk
+    hipLaunchKernelGGL((igemm_nt_v2_persist_kernel<WGM, WM, WN, AFF>), dim3(slots), dim3(256), 0, st, p, (int)total,
+                       AFF == 4 ? (int)total : per_batch);
+    return true;
+}
+
 template <int MODE>
 static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
     if constexpr (MODE == 2) {
@@ -1039,7 +1090,7 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
             if (cfg == 12) {
                 int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
                 hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, 2, 1, 0, 4>), dim3(tiles * 16), dim3(256), 0, st, p);
-            } else {
+            } else if (!launch_nt_persist<1, 3, 1, 4>(p, 96, 128, 16, st)) {
                 int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
                 hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, 2, 1, 0, 4>), dim3(tiles * 16), dim3(256), 0, st, p);
             }
@@ -1086,11 +1137,14 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
         // measured: short reductions (K <= 1024, i.e. the 1x1 convs) gain ~10 % from the higher residency of the
         // single-buffer variant (3 workgroups/CU); long ones gain 2-5 % from the second buffer (one barrier per tile)
         static const int nbuf1_max_k = getenv("VSPW_NBUF1_MAXK") ? atoi(getenv("VSPW_NBUF1_MAXK")) : 1024;
+        if (MODE == 2 && p.kdim <= nbuf1_max_k && launch_nt_persist<2, 2, 2, 0>(p, 128, 128, p.batch, st))
+            return;
         if (p.kdim <= nbuf1_max_k)
             hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
         else
             hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 2>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     } else if (cfg == 31) {
+        if (MODE == 2 && launch_nt_persist<1, 3, 1, 0>(p, 96, 128, p.batch, st)) return;
         int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
         hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     } else if (cfg == 12) {
@@ -1128,12 +1182,6 @@ static int launch_igemm_nt(const IgemmNT& pin, hipStream_t st) {
     bool v2;
     IgemmNT p = pin;
     const int cfg = nt_decide(p, v2);
-    {   // experiment knobs: VSPW_STAGGER="unit,div,mod,n"
-        static const char* sg = getenv("VSPW_STAGGER");
-        if (sg) sscanf(sg, "%d,%d,%d,%d", &p.stagger_unit, &p.stagger_div, &p.stagger_mod, &p.stagger_n);
-        if (p.stagger_mod < 1) p.stagger_mod = 1;
-        if (p.stagger_div < 1) p.stagger_div = 1;
-    }
     if (v2) {
         const bool pw = p.kh * p.kw == 1 && p.stride == 1 && p.pad == 0 && p.padw == 0;
         if (pw)
@@ -1850,7 +1898,6 @@ static bool fill_fwd_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
     p.src2 = nullptr; p.coef = nullptr; p.zout = nullptr;
     p.batch = 1; p.bs_src = p.bs_wt = p.bs_dst = 0;
-    p.stagger_n = p.stagger_div = p.stagger_mod = p.stagger_unit = 0;
     p.wino_d = p.wino_th = p.wino_tw = 0;
 #ifdef VSPW_NT_DBG
     p.dbg = getenv("VSPW_NT_DBG") ? atoi(getenv("VSPW_NT_DBG")) : 0;
@@ -1993,7 +2040,6 @@ static bool fill_bwd_data_params(const vspw_conv_desc* d, IgemmNT& p) {
     p.relu_src = nullptr; p.bn_y = nullptr; p.bn_mean = nullptr; p.bn_invstd = nullptr;
     p.src2 = nullptr; p.coef = nullptr; p.zout = nullptr;
     p.batch = 1; p.bs_src = p.bs_wt = p.bs_dst = 0;
-    p.stagger_n = p.stagger_div = p.stagger_mod = p.stagger_unit = 0;
     p.wino_d = p.wino_th = p.wino_tw = 0;
 #ifdef VSPW_NT_DBG
     p.dbg = getenv("VSPW_NT_DBG") ? atoi(getenv("VSPW_NT_DBG")) : 0;

@@ -1,4 +1,4 @@
-"""Start-stagger experiment for short-K GEMMs: VSPW_STAGGER="unit,div,mod,n" (read once per process)."""
+"""Time vspw_bmm_nt on the short-K shapes of the bench step (env knobs of the launcher apply: VSPW_PERSIST, ...)."""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -15,8 +15,9 @@ def timeit(fn, iters=40):
     return e0.elapsed_time(e1) / iters * 1e3
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 out = []
-for name, B, M, N, K in (("wino256", 16, 9000, 256, 256), ("wino512d4", 16, 10240, 512, 512), ("pw256->1024", 1, 36000, 1024, 256), ("pw1024->256", 1, 36000, 256, 1024)):
+for name, B, M, N, K in (("wino256", 16, 9000, 256, 256), ("wino512d4", 16, 10240, 512, 512), ("pw256->1024", 1, 36000, 1024, 256),
+                         ("pw1024->256", 1, 36000, 256, 1024), ("pw512->2048", 1, 36000, 2048, 512)):
     a = torch.randn(B, M, K, device=dev); b = torch.randn(B, N, K, device=dev); c = torch.empty(B, M, N, device=dev)
     us = timeit(lambda: _C.call("vspw_bmm_nt", a.data_ptr(), b.data_ptr(), c.data_ptr(), B, M, N, K, st))
     out.append("%s %.1f us %.1f TF" % (name, us, 2.0 * B * M * N * K / us / 1e6))
-print("%-16s" % os.environ.get("VSPW_STAGGER", "none"), " | ".join(out))
+print("PERSIST=%s" % os.environ.get("VSPW_PERSIST", "default"), " | ".join(out))

@@ -42,3 +42,25 @@ def test_bench_refuses_more_ranks_than_devices(dev):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"], env=env,
                        cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
+
+
+def test_bench_reports_collective_diagnostics_with_a_one_rank_rccl_group(dev):
+    """VSPW_FORCE_COLLECTIVES=1: the N > 1 code path (RCCL process group, SyncBN exchange per BatchNorm, bucketed
+    all-reduce) on the one GPU of the box.  `auto` must pick eager launches when a process group is alive (a captured
+    step can abort the process through ProcessGroupNCCL's watchdog, bench.py main()), and the line must carry the
+    `collectives` diagnostics a real scaling run will be read with."""
+    env = dict(os.environ, VSPW_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    env.pop("VSPW_BENCH_SHARED_GPU", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--no-host-probe"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["config"]["execution"] == "eager launches" and out["config"]["rccl_ranks"] == 1
+    c = out["collectives"]
+    assert c["syncbn_exchanges_per_step"] == 224            # 112 BatchNorm layers, forward + backward
+    assert 0.5 < c["syncbn_exchange_ms_per_step"] < 50.0
+    assert c["grad_buckets"] >= 8 and c["allreduce_exposed_ms_per_step"] >= 0.0
+    assert c["rccl_graph_capture"] is None and c["sync_bn"] is True and c["sync_bn_formula"] == "var+eps"
+    assert out["roofline"]["effective_direct_conv_tflops"] > out["roofline"]["achieved"]  # Winograd launches counted

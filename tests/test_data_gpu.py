@@ -1,6 +1,7 @@
 """Input pipeline on the device (csrc/data.hip through cvpr2021_vspw_implement_amd.dataset2.DeviceTransform): the
 tensors handed to the model equal, bit for bit, what the reference's dataset2.py classes produce on the CPU
 (tests/golden/vspw_datasets.npz) - decode on the host, everything after it in HIP kernels."""
+import os
 import random
 
 import numpy as np
@@ -95,3 +96,23 @@ def test_loader_with_workers_and_no_cpu_fallback(dev, tree):
     assert n == 1
     with pytest.raises(RuntimeError):
         D.DeviceTransform("cpu")
+
+
+def test_pipeline_bench_smoke(dev, tmp_path):
+    """tools/pipeline_bench.py end to end on a small synthetic VSPW tree: JPEG decode in 2 DataLoader workers ->
+    DeviceTransform (HIP) -> TCB-PSP R101 training steps fed by the loader (reference
+    dataset2.py:852-1048)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "pipeline_bench.py"), "--videos", "6", "--frames", "14",
+                        "--workers", "2", "--steps", "2", "--root", str(tmp_path / "tree")], capture_output=True,
+                       text=True, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["loader"][0]["workers"] == 2 and out["loader"][0]["clips_per_s"] > 0
+    assert out["transform"]["ms_per_batch_stream"] > 0 and out["transform"]["bytes_out"] == 2 * 5 * 479 * 479 * 16
+    e2e = out["end_to_end"][0]
+    assert e2e["workers"] == 2 and e2e["ms_per_step"] >= 0.8 * out["resident_ms_per_step"]

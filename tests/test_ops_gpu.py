@@ -256,6 +256,34 @@ def test_batchnorm_tiny_population_with_nearly_equal_samples(dev, fused):
     assert ((rv.double().cpu() - (0.9 + 0.1 * var_u)).abs() / (0.9 + 0.1 * var_u)).max() < 1e-6
 
 
+def test_bn_finalize_clamped_is_the_reference_multi_device_formula(dev):
+    """vspw_bn_finalize_clamped: invstd = clamp(var_biased, eps)^-1/2 (reference models/sync_batchnorm/batchnorm.py:150,
+    the multi-device path), against the plain (var + eps)^-1/2 of vspw_bn_finalize, on channels with variances on both
+    sides of eps; running statistics are the same in both."""
+    import ctypes
+
+    from cvpr2021_vspw_implement_amd import _C
+
+    c, count, eps = 8, 50.0, 1e-5
+    mean = torch.linspace(-1, 1, c, dtype=torch.float64)
+    var = torch.tensor([0.0, 1e-7, 5e-6, 1e-5, 2e-5, 1e-3, 0.5, 3.0], dtype=torch.float64)
+    sums = torch.stack([mean * count, (var + mean * mean) * count]).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = {}
+    for name in ("vspw_bn_finalize", "vspw_bn_finalize_clamped"):
+        g, b = torch.ones(c, device=dev), torch.zeros(c, device=dev)
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        co = torch.empty(4, c, device=dev)
+        _C.call(name, sums.data_ptr(), ctypes.c_double(count), g.data_ptr(), b.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1,
+                eps, co[0].data_ptr(), co[1].data_ptr(), co[2].data_ptr(), co[3].data_ptr(), c, st)
+        outs[name] = (co.double().cpu(), rm.double().cpu(), rv.double().cpu())
+    plain, clamped = outs["vspw_bn_finalize"], outs["vspw_bn_finalize_clamped"]
+    assert torch.allclose(plain[0][1], (var + eps).rsqrt(), rtol=1e-5)           # sums carry ~1e-9 cancellation noise
+    assert torch.allclose(clamped[0][1], var.clamp(min=eps).rsqrt(), rtol=1e-4)
+    assert torch.equal(plain[1], clamped[1]) and torch.equal(plain[2], clamped[2])
+    assert torch.allclose(plain[0][0], mean, atol=1e-6)
+
+
 def test_conv_bn_act_fused_and_dropout(dev):
     from cvpr2021_vspw_implement_amd import ops
 

@@ -225,3 +225,50 @@ def run_oracle_jobs(jobs, workdir, parallel=None, threads=None, mem_gb=None):
         elif pending and all(jobs[i].get("after") is not None and jobs[i]["after"] not in done for i in pending):
             raise RuntimeError("oracle jobs wait for jobs that never ran: %r" % pending)
     return [np.load(job["out"]) for job in jobs]
+
+
+# ------------------------------------------------------------------------------------------------------ pinned decisions
+def hip_decision_store(mod, taps):
+    """ops.record_decisions taps of one HIP forward -> {oracle key: [arrays]} (see oracle.np_ops.set_decisions)."""
+    bn_name = {id(p): n[:-len(".weight")] for n, p in mod.named_parameters() if n.endswith(".weight")}
+    store = {}
+    for what, key, t in taps:
+        if what == "relu":
+            store.setdefault(bn_name[id(key)], []).append((t > 0).cpu().numpy())
+        else:  # max-pool taps [n, oh, ow, c] -> the oracle's [n, c, oh, ow]
+            store.setdefault("encoder.maxpool", []).append(t.permute(0, 3, 1, 2).contiguous().cpu().numpy().astype(np.int8))
+    return store
+
+
+def oracle_train(fn, sd, dt, gemm="blas", decisions=None, store=None):
+    """One oracle training step: fn(P) -> (loss Var, acc).  Returns (loss, {name: float64 gradient})."""
+    from oracle import np_models as NM
+    from oracle import np_ops as O
+
+    O.set_dtype(dt)
+    O.set_gemm(gemm)
+    O.set_decisions(decisions, store)
+    try:
+        P = NM.Params({k: (v.astype(dt) if v.dtype.kind == "f" else v.copy()) for k, v in sd.items()}, train_params=True)
+        loss, _ = fn(P, dt)
+        O.tape().backward(loss)
+        return float(np.asarray(loss.v).reshape(())), {k: v.astype(np.float64) for k, v in P.grads().items()}
+    finally:
+        O.set_decisions(None)
+        O.set_gemm("blas")
+        O.set_dtype(np.float32)
+
+
+def pinned_gradient_errors(fn, sd, hip_store, hip_grads):
+    """Per-parameter relative L2 of the HIP gradients against the float64 oracle with the HIP forward's decisions
+    injected, next to the same for the float32 oracle (GEMMs in matrix-core accumulation order) with ITS decisions:
+    (names, e_hip, e_oracle).  See tests/test_fullsize_gpu.py for the rationale."""
+    _, g64h = oracle_train(fn, sd, np.float64, decisions="inject", store=hip_store)
+    rec = {}
+    _, g32 = oracle_train(fn, sd, np.float32, gemm="sequential", decisions="record", store=rec)
+    _, g64o = oracle_train(fn, sd, np.float64, decisions="inject", store=rec)
+    names = sorted(g64h)
+    scale = max(float(np.linalg.norm(v)) for v in g64h.values())
+    rel = lambda a, b: np.array([float(np.linalg.norm(a[n].astype(np.float64) - b[n]))  # noqa: E731
+                                 / max(float(np.linalg.norm(b[n])), 1e-3 * scale) for n in names])
+    return names, rel(hip_grads, g64h), rel(g32, g64o)

@@ -187,6 +187,14 @@ def run_oracle_jobs(jobs, workdir, parallel=None, threads=None, mem_gb=None):
             mem_gb = psutil.virtual_memory().available / 2 ** 30
         except Exception:
             mem_gb = 64.0
+        for lim, use in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                         ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+            try:  # a container limit below what the host reports (the box dies, it does not swap)
+                lv = open(lim).read().strip()
+                if lv != "max" and int(lv) < 2 ** 60:
+                    mem_gb = min(mem_gb, (int(lv) - int(open(use).read().strip())) / 2 ** 30)
+            except Exception:
+                pass
     budget = 0.6 * mem_gb
     env = dict(os.environ, OPENBLAS_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads), PYTHONDONTWRITEBYTECODE="1",
                HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")

@@ -1165,6 +1165,8 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
 // buffers, the smaller tiles one (two would cap residency at 2 workgroups/CU and lose)
 static int nt_decide(const IgemmNT& p, bool& v2) {
     int cfg = nt_pick_tile(p.m, p.nout, p.batch);
+    static const int force_cfg = getenv("VSPW_NT_CFG") ? atoi(getenv("VSPW_NT_CFG")) : 0;  // experiments: 22 / 31 / 12 / 21 / 11
+    if (force_cfg) cfg = force_cfg;
     // the fused BatchNorm-backward front end makes the epilogue a long memory phase (three extra operand streams): the
     // 96-row tile (48 accumulators, one more resident workgroup to overlap it with) beats 128x128 there (-10 %)
     if (p.relu_src != nullptr && cfg == 22) cfg = 31;

@@ -18,8 +18,7 @@ ProcessGroupNCCL's watchdog thread - see main(); `--mode graph` forces the captu
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events recorded on the launch stream around every
 launch of the dominant kernel (igemm_nt_kernel: all convolution forward and data-gradient GEMMs, ~2/3 of the step's
-FLOPs) on timed steps executed eagerly inside the timed region (graph mode: the last timed step; eager mode: first,
-middle, last); `cpu_baseline` times the numpy oracle (a port of the reference's arithmetic, test infrastructure) on a
+FLOPs) on the last timed step, executed eagerly inside the timed region; `cpu_baseline` times the numpy oracle (a port of the reference's arithmetic, test infrastructure) on a
 bounded sample on rank 0 at N=1.
 """
 import argparse
@@ -311,16 +310,14 @@ def main():
     if graphed is not None and not args.no_kernel_timing:
         loss = run_step(args.warmup, eager=True)  # warm the eager path too (allocator, lazily built tables)
     barrier()
-    # per-launch HIP events (two per GEMM launch) need eagerly issued launches: graph mode runs the LAST timed step
-    # eagerly, eager mode samples first / middle / last (the events cost ~2 % of a step); --kernel-report: every step
+    # per-launch HIP events (two per GEMM launch) need eagerly issued launches: the LAST timed step carries them (graph
+    # mode issues that step eagerly); --kernel-report: every step
     if args.no_kernel_timing:
         timed_steps = set()
     elif args.kernel_report or args.steps <= 2:
         timed_steps = set(range(args.steps))
-    elif graphed is not None:
+    else:  # ONE sampled step: it runs with per-launch events and without the weight-gradient side stream (~10 % slower)
         timed_steps = {args.steps - 1}
-    else:
-        timed_steps = {0, args.steps // 2, args.steps - 1}
     ops.kernel_timer(False)
     ops.kernel_timer_reset()
     bn_events, red_events = [], {}

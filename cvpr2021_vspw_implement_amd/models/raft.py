@@ -102,6 +102,9 @@ class _BasicUpdateBlock(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ launch helpers
+GEMM_FLOPS = {"total": 0.0}  # algorithmic FLOPs of the MFMA launches issued so far (tools/raft_bench.py reads / resets it)
+
+
 def _conv(x, n, h, w, c, ldx, wt, bias, kh, kw, stride, pad, act, y, ldy):
     """One vspw_conv2d_fwd_ex launch.  x: device pointer holder of an NHWC buffer [n][h][w][ldx] read from its first
     `c` channels on; wt [K][KH][KW][C] packed; y written with row stride ldy.  Returns (oh, ow)."""
@@ -110,6 +113,7 @@ def _conv(x, n, h, w, c, ldx, wt, bias, kh, kw, stride, pad, act, y, ldy):
     oh = (h + 2 * ph - (kh - 1) - 1) // stride + 1
     ow = (w + 2 * pw - (kw - 1) - 1) // stride + 1
     d = ConvDesc(n, h, w, c, oh, ow, k, kh, kw, stride, ph, 1, pw)
+    GEMM_FLOPS["total"] += 2.0 * n * oh * ow * k * kh * kw * c
     _C.call("vspw_conv2d_fwd_ex", ctypes.byref(d), x, ldx, _p(wt), _p(bias), None, act, y, ldy, _stream())
     return oh, ow
 
@@ -278,6 +282,7 @@ class RAFT(nn.Module):
         _C.call("vspw_axpby", _p(f1), _p(f1), f1.numel(), 1.0 / math.sqrt(256.0), 0.0, _stream())
         pyr = [torch.empty((rows, hw), **f32)]
         # corr[b] = fmap1[b] @ fmap2[b]^T for every pair in one batched launch
+        GEMM_FLOPS["total"] += 2.0 * N * hw * hw * 256
         _C.call("vspw_bmm_nt", _p(fmap[:N]), _p(fmap[N:]), _p(pyr[0]), N, hw, hw, 256, _stream())
         lh, lw = h8, w8
         for _ in range(self.corr_levels - 1):

@@ -8,6 +8,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cvpr2021_vspw_implement_amd.models import raft as raft_mod  # noqa: E402
 from cvpr2021_vspw_implement_amd.models.raft import RAFT  # noqa: E402
 
 
@@ -22,13 +23,17 @@ def main():
         m(a, b, iters=iters, test_mode=True)
     torch.cuda.synchronize()
     reps = 5
+    raft_mod.GEMM_FLOPS["total"] = 0.0
     t0 = time.perf_counter()
     for _ in range(reps):
         low, up = m(a, b, iters=iters, test_mode=True)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / reps * 1e3
+    gflop = raft_mod.GEMM_FLOPS["total"] / reps / 1e9  # convolutions + the all-pairs correlation GEMM
     print(json.dumps({"workload": "RAFT-basic forward, B=2 pairs, 480x856, iters=20", "ms_per_forward": round(ms, 2),
-                      "pairs_per_s": round(B / ms * 1e3, 2), "finite": bool(torch.isfinite(up).all().item())}))
+                      "pairs_per_s": round(B / ms * 1e3, 2), "gemm_gflop_per_forward": round(gflop, 1),
+                      "effective_tflops": round(gflop / ms, 1), "frac_of_fp32_mfma_peak": round(gflop / ms / 157.3, 3),
+                      "finite": bool(torch.isfinite(up).all().item())}))
 
 
 if __name__ == "__main__":

@@ -354,7 +354,7 @@ def test_bench_workload_against_fp32_ensemble(bench_case):
 
 @pytest.mark.skipif(os.environ.get("VSPW_FULLSIZE_479") != "1",
                     reason="opt-in (VSPW_FULLSIZE_479=1): three oracle evaluations at 479x479, ~15 minutes")
-@pytest.mark.parametrize("kind", ["clip_psp"])
+@pytest.mark.parametrize("kind", ["clip_psp", "clip_ocr"])
 def test_pinned_decisions_at_the_metrics_own_crop_size(dev, kind, tmp_path):
     """The pinned-decision comparison of test_bench_workload_gradients_with_pinned_decisions at EXACTLY the bench
     workload (R101, T = 5, B = 2, 479x479: 60x60 feature maps, BatchNorm populations of 36 000) - one rounding

@@ -216,7 +216,10 @@ def run_oracle_jobs(jobs, workdir, parallel=None, threads=None, mem_gb=None):
             jp = os.path.join(workdir, "job_%s.json" % os.path.basename(out))
             with open(jp, "w") as f:
                 json.dump(job, f)
-            running[i] = subprocess.Popen([sys.executable, worker, jp], env=env)
+            jenv = env
+            if job.get("threads"):  # e.g. the jobs at the end of a dependency chain, which run when the pool is empty
+                jenv = dict(env, OPENBLAS_NUM_THREADS=str(job["threads"]), OMP_NUM_THREADS=str(job["threads"]))
+            running[i] = subprocess.Popen([sys.executable, worker, jp], env=jenv)
             used += job.get("mem_gb", 0.0)
         for i, p in list(running.items()):
             rc = p.poll()

@@ -123,7 +123,7 @@ class _NetWarpBase(LrGroupsMixin, nn.Module):
     def _warp_blend(self, feats, flow, w_cur, w_warp):
         """feats = [current; previous] stacked on the batch: blend the current half with the flow-warped previous."""
         B = feats.shape[0] // 2
-        cur, prev = feats[:B], feats[B:]
+        cur, prev = ops.split_batch(feats, B)
         flow_s = F.interpolate(flow, cur.shape[-2:], mode="nearest")  # nearest, magnitudes NOT rescaled (quirk)
         return ops.chan_blend(cur, ops.flowwarp(prev, flow_s), w_cur, w_warp), prev
 
@@ -160,7 +160,8 @@ class NetWarp(_NetWarpBase):
         ignore = nll_ignore_index(self.crit)
         loss, acc = ops.seg_nll(pred_, label, ignore, want_acc=True, from_logits=True)
         if self.deep_sup_scale is not None:
-            loss_deepsup, _ = ops.seg_nll(pred_deepsup_s[:B], label, ignore, want_acc=False, from_logits=False)
+            loss_deepsup, _ = ops.seg_nll(ops.split_batch(pred_deepsup_s, B)[0], label, ignore, want_acc=False,
+                                          from_logits=False)
             loss = loss + loss_deepsup * self.deep_sup_scale
         return loss, acc
 

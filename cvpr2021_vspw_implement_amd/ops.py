@@ -1181,6 +1181,40 @@ def tail_frames(x, count):
     return TailFramesFn.apply(x, count)
 
 
+class SplitBatchFn(torch.autograd.Function):
+    """(x[:b], x[b:]) of an NHWC-memory tensor as zero-copy slabs (NetWarp: [current; previous] stacked on the batch,
+    reference models/netwarp.py:196-203).  The gradient of both halves lands in ONE NHWC buffer by two contiguous copies;
+    autograd's own slice-backward builds two zero-filled full-size tensors, fills them through strided element-wise
+    kernels and adds them (measured on the NetWarp step: 21 + 8 launches, 1.05 ms)."""
+
+    @staticmethod
+    def forward(ctx, x, b):
+        _require_gpu(x, "split_batch")
+        x = to_nhwc(x)
+        ctx.meta = (tuple(x.shape), int(b))
+        return x[:b], x[b:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        (n, c, h, w), b = ctx.meta
+        dx = empty_nhwc(n, c, h, w, (ga if ga is not None else gb).device)
+        st = _stream()
+        for part, g in ((dx[:b], ga), (dx[b:], gb)):
+            if g is None:
+                part.zero_()
+            else:
+                g = to_nhwc(g)
+                _C.call("vspw_axpby", _p(g), _p(part), g.numel(), 1.0, 0.0, st)
+        return dx, None
+
+
+def split_batch(x, b):
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        x = to_nhwc(x)
+        return x[:b], x[b:]
+    return SplitBatchFn.apply(x, b)
+
+
 class PPMConcatFn(torch.autograd.Function):
     """torch.cat([conv5] + [bilinear_up(branch_i)], dim=1) written straight into one NHWC buffer
     (models/clip_psp.py:45-53)."""

@@ -57,6 +57,9 @@ def parse_args():
     ap.add_argument("--kernel-report", default="", help="write a per-shape GEMM efficiency table to this file "
                                                         "(every timed step runs eagerly with per-launch events)")
     ap.add_argument("--method", default="clip_psp", choices=["clip_psp", "clip_ocr"])
+    ap.add_argument("--crop", type=int, default=CROP,
+                    help="crop size; anything but 479 is NOT the metric's workload (plumbing tests use small crops) and "
+                         "the line says so")
     ap.add_argument("--no-sync-bn", action="store_true",
                     help="N > 1: every rank normalises with its own batch statistics (no per-layer exchange)")
     ap.add_argument("--sync-bn-clamp-var", action="store_true",
@@ -201,6 +204,20 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))
 
+    # Multi-rank runs carry a phase log + hang watchdog (cvpr2021_vspw_implement_amd/watchdog.py): a rank that makes
+    # no progress for 120 s dumps its Python stacks, rank 0 prints a JSON line with "error", and the process exits 3.
+    from cvpr2021_vspw_implement_amd import watchdog
+
+    env_rank = int(os.environ.get("RANK", "0"))
+
+    def on_hang(phase_name):
+        if env_rank == 0:
+            print(json.dumps({"metric": "480p clips/s (T=5, B=2/GPU) train fwd+bwd", "value": None, "unit": "clips/s",
+                              "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                              "error": "watchdog: no progress in phase %r" % phase_name}), flush=True)
+
+    wd = watchdog.make(args.gpus > 1 or os.environ.get("VSPW_FORCE_COLLECTIVES") == "1", 120.0, on_hang)
+    wd.phase("import torch", 600)  # the first import on a fresh box pages the image in (minutes)
     import torch
 
     from cvpr2021_vspw_implement_amd import distributed as vdist
@@ -210,6 +227,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the hot path has no CPU fallback")
+    wd.phase("init process group", 300)
     rank, local_rank, world = vdist.init_from_env()  # (test mode: gloo, LOCAL_RANK folded onto the visible devices)
     if world != args.gpus:
         raise RuntimeError("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -219,6 +237,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    wd.phase("build model")
     torch.manual_seed(304)
     margs = types.SimpleNamespace(num_class=K_CLASSES, psp_weight=False, use_memory=False, memory_num=0,
                                   clipocr_all=False, clip_num=T_FRAMES)
@@ -237,10 +256,11 @@ def main():
         work_stream = torch.cuda.Stream()
         work_stream.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(work_stream)
+    wd.phase("broadcast parameters")
     model = vdist.DataParallelOverRCCL(net, force_collectives=force, sync_bn=not args.no_sync_bn,
                                        sync_bn_clamp_var=args.sync_bn_clamp_var)
     opt = optim.create_optimizers(net, lr=0.002, weight_decay=1e-4, momentum=0.9)
-    imgs, labs = make_inputs(dev, 304 + rank)
+    imgs, labs = make_inputs(dev, 304 + rank, crop=args.crop)
     max_iters = 1000
 
     def step_body(im, lb):
@@ -275,6 +295,7 @@ def main():
         # invalidates the capture and aborts the PROCESS - not an exception this code could catch.  8 % is not worth a
         # run that dies; `--mode graph` still takes the captured path (after the preflight below).
         mode = "eager" if collectives else "graph"
+    wd.phase("capture / preflight (mode %s)" % mode, 300)
     if mode == "graph" and collectives:
         rccl_capture = rccl_capture_preflight(dev)
         if not rccl_capture:
@@ -306,7 +327,9 @@ def main():
         return graphed.replay()
 
     for i in range(args.warmup):
+        wd.phase("warm-up step %d issue" % i)
         loss = run_step(i)
+    wd.phase("warm-up drain + barrier")
     if graphed is not None and not args.no_kernel_timing:
         loss = run_step(args.warmup, eager=True)  # warm the eager path too (allocator, lazily built tables)
     barrier()
@@ -328,17 +351,20 @@ def main():
         if collectives:  # HIP events around every collective of the eagerly issued (sampled) steps
             ops.sync_bn_timer(bn_events if ev else None)
             model.reducer.timer = red_events if ev else None
+        wd.phase("timed step %d issue" % i)
         loss = run_step(args.warmup + 1 + i, eager=ev)
     host_enqueue = time.perf_counter() - t0  # host time to enqueue all K steps (GPU still running)
+    wd.phase("timed region drain + barrier")
     barrier()
     elapsed = time.perf_counter() - t0
     ops.kernel_timer(False, reset=False)
     ops.sync_bn_timer(None)
     model.reducer.timer = None
+    wd.phase("max-over-ranks timing")
     last_loss = float(loss.item())
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        vdist.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
     roofline = None
@@ -431,10 +457,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (seed 304), random-init weights",
-            "config": {"workload": "TCB-PSP (Clip_PSP, resnet101dilated) train step: T=5 frames, B=2 clips/GPU, "
-                                   "479x479 crop, 124 classes, fwd+loss+bwd+SGD (vsp-resnet101dilated-ppm_deepsup_clip)"
-                       if args.method == "clip_psp" else
-                       "TCB-OCR (ClipOCRNet, resnet101dilated) train step: T=5, B=2/GPU, 479x479, 124 classes",
+            "config": {"workload": ("TCB-PSP (Clip_PSP, resnet101dilated) train step: T=5 frames, B=2 clips/GPU, "
+                                    "%dx%d crop, 124 classes, fwd+loss+bwd+SGD (vsp-resnet101dilated-ppm_deepsup_clip)"
+                                    if args.method == "clip_psp" else
+                                    "TCB-OCR (ClipOCRNet, resnet101dilated) train step: T=5, B=2/GPU, %dx%d, 124 classes")
+                       % (args.crop, args.crop)
+                       + ("" if args.crop == CROP else " - NOT the metric's 479x479 workload (--crop): plumbing only"),
                        "global_batch_clips": world * B_CLIPS, "frames_per_step_per_gpu": T_FRAMES * B_CLIPS,
                        "parallelism": "dp%d" % world, "sync_bn": collectives and not args.no_sync_bn,
                        "rccl_ranks": 0 if SHARED_GPU_TEST else (
@@ -444,7 +472,8 @@ def main():
                                       "not a measurement"} if SHARED_GPU_TEST else {})},
             # direct-convolution FLOPs of the step (5785 GFLOP/clip) per second against the fp32 MFMA
             # peak: an EFFECTIVE fraction - the Winograd path executes 4/9 of the multiplications of its 3x3 convs
-            "e2e_mfma_frac": round(GFLOP_PER_CLIP * 1e9 * clips_per_s / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
+            "e2e_mfma_frac": round(GFLOP_PER_CLIP * 1e9 * clips_per_s / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+            if args.crop == CROP else None,
             "last_loss": round(last_loss, 5),
             "host_enqueue_ms_per_step": round(host_enqueue / args.steps * 1e3, 2),
             "host_probe": host_probe,
@@ -454,8 +483,10 @@ def main():
             out["collectives"] = comm
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_size, full=args.cpu_baseline_full)
+    wd.phase("destroy process group")
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    wd.stop()
     if rank == 0:
         # RCCL prints a version banner through C stdio (buffered when piped): flush it first so that the JSON line is
         # the LAST line of stdout

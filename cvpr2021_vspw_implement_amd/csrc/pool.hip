@@ -551,3 +551,67 @@ extern "C" int vspw_temporal_mean_bwd(const float* dy, const float* wts, float* 
                        dy, wts, dx, T, B, inner);
     return vspw_launch_status();
 }
+
+// ---- 2x2 average pool, NHWC ------------------------------------------------------------------------
+// F.avg_pool2d(emb, (2,2)) of the non-local decoders' `downsample` switch (models/non_local_models.py:30-32,136-137):
+// stride 2, no padding, floor output size (an odd trailing row / column is dropped); ATen sums the window row-major
+// and divides by 4.  One thread per 4 channels; the adjoint is a gather (each input pixel belongs to one window).
+__global__ __launch_bounds__(256) void avgpool2x2_nhwc_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  int n, int h, int w, int c4, int oh, int ow) {
+    const long long total = (long long)n * oh * ow * c4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const f32x4* __restrict__ x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* __restrict__ y4 = reinterpret_cast<f32x4*>(y);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int ch = (int)(i % c4);
+        long long r = i / c4;
+        const int ox = (int)(r % ow);
+        r /= ow;
+        const int oy = (int)(r % oh);
+        const int img = (int)(r / oh);
+        const size_t base = (((size_t)img * h + 2 * oy) * w + 2 * ox) * c4 + ch;
+        f32x4 acc = x4[base];
+        acc += x4[base + c4];
+        acc += x4[base + (size_t)w * c4];
+        acc += x4[base + (size_t)w * c4 + c4];
+        y4[i] = acc * 0.25f;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool2x2_nhwc_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                  int n, int h, int w, int c4, int oh, int ow) {
+    const long long total = (long long)n * h * w * c4;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const f32x4* __restrict__ g4 = reinterpret_cast<const f32x4*>(dy);
+    f32x4* __restrict__ d4 = reinterpret_cast<f32x4*>(dx);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int ch = (int)(i % c4);
+        long long r = i / c4;
+        const int ix = (int)(r % w);
+        r /= w;
+        const int iy = (int)(r % h);
+        const int img = (int)(r / h);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((iy >> 1) < oh && (ix >> 1) < ow)
+            v = g4[(((size_t)img * oh + (iy >> 1)) * ow + (ix >> 1)) * c4 + ch] * 0.25f;
+        d4[i] = v;
+    }
+}
+
+extern "C" int vspw_avgpool2x2_nhwc_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream) {
+    if (!x || !y || n <= 0 || h < 2 || w < 2 || c <= 0 || (c & 3)) return VSPW_EINVAL;
+    const int oh = h / 2, ow = w / 2;
+    const long long total = (long long)n * oh * ow * (c / 4);
+    hipLaunchKernelGGL(avgpool2x2_nhwc_fwd_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream),
+                       x, y, n, h, w, c / 4, oh, ow);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_avgpool2x2_nhwc_bwd(const float* dy, float* dx, int n, int h, int w, int c, void* stream) {
+    if (!dy || !dx || n <= 0 || h < 2 || w < 2 || c <= 0 || (c & 3)) return VSPW_EINVAL;
+    const int oh = h / 2, ow = w / 2;
+    const long long total = (long long)n * h * w * (c / 4);
+    hipLaunchKernelGGL(avgpool2x2_nhwc_bwd_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream),
+                       dy, dx, n, h, w, c / 4, oh, ow);
+    return vspw_launch_status();
+}

@@ -24,6 +24,39 @@ def shared_gpu_test():
     return os.environ.get("VSPW_SHARED_GPU_TEST") == "1" or os.environ.get("VSPW_BENCH_SHARED_GPU") == "1"
 
 
+class _Completed:
+    """Handle of a collective that has already finished (test mode below)."""
+
+    def wait(self):
+        return True
+
+
+def all_reduce(t, op=None, group=None, async_op=False):
+    """torch.distributed.all_reduce.  Production (RCCL): passed straight through.  In the shared-GPU TEST MODE a device
+    tensor is staged through host memory by this function - .cpu() (ordered after the tensor's producers on the current
+    stream), a gloo all-reduce of the host copy, a copy back - instead of handing the device tensor to
+    ProcessGroupGloo, whose own side streams / pinned staging pool / worker threads are one more moving part between
+    two processes that share a device and are not what that mode is there to exercise (launcher, rendezvous,
+    broadcast, SyncBN exchange points, bucketing, max-over-ranks timing, rank-0 reporting)."""
+    op = dist.ReduceOp.SUM if op is None else op
+    if t.is_cuda and shared_gpu_test():
+        host = t.detach().cpu()
+        dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+        return _Completed() if async_op else None
+    return dist.all_reduce(t, op=op, group=group, async_op=async_op)
+
+
+def broadcast(t, src=0, group=None):
+    """torch.distributed.broadcast; host-staged in the shared-GPU test mode (see all_reduce)."""
+    if t.is_cuda and shared_gpu_test():
+        host = t.detach().cpu()
+        dist.broadcast(host, src=src, group=group)
+        t.copy_(host)
+        return None
+    return dist.broadcast(t, src=src, group=group)
+
+
 def init_from_env(backend=None):
     """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -38,12 +71,17 @@ def init_from_env(backend=None):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if os.environ.get("VSPW_DIST_TIMEOUT_S"):  # collectives raise instead of blocking forever (test modes)
+            import datetime
+
+            kw["timeout"] = datetime.timedelta(seconds=float(os.environ["VSPW_DIST_TIMEOUT_S"]))
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
+                                    device_id=torch.device("cuda", local_rank), **kw)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
 
@@ -109,7 +147,7 @@ class GradReducer:
             return
         for t in list(module.parameters()) + list(module.buffers()):
             if t.is_floating_point() or t.dtype == torch.long:
-                dist.broadcast(t.data, src=src, group=self.group)
+                broadcast(t.data, src=src, group=self.group)
 
     def _launch(self, bi):
         """Gather the bucket's gradients into its flat buffer with ONE multi-tensor copy, then start the all-reduce."""
@@ -133,7 +171,7 @@ class GradReducer:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
             self.timer.setdefault("launch", {})[bi] = e0
-        self.handles[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.handles[bi] = all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
         bi = self.owner[id(p)]

@@ -14,8 +14,6 @@ from .non_local import NLBlockND
 class Non_local3d(LrGroupsMixin, nn.Module):
     def __init__(self, args, net_enc, crit, downsample=False):
         super().__init__()
-        if downsample:
-            raise NotImplementedError("the avg-pool `downsample` switch is not on the HIP path")
         self.encoder = net_enc
         self.downsample = downsample
         self.crit = crit
@@ -42,9 +40,14 @@ class Non_local3d(LrGroupsMixin, nn.Module):
         n, c, h, w = emb.shape
         B = n // clip_num
         # [T*B,C,h,w] -> [B,C,T,h,w]: data movement only (torch views + one gather copy)
-        x = emb.reshape(clip_num, B, c, h, w).permute(1, 2, 0, 3, 4)
+        # `downsample` (reference :30-32,43-44): affinity on the 2x2-average-pooled embedding, bilinear back up
+        emb_ = ops.avg_pool2x2(emb) if self.downsample else emb
+        hs, ws = emb_.shape[-2:]
+        x = emb_.reshape(clip_num, B, c, hs, ws).permute(1, 2, 0, 3, 4)
         x = self.nonlocalblock(x)
-        x = x.permute(2, 0, 1, 3, 4).reshape(n, c, h, w)
+        x = x.permute(2, 0, 1, 3, 4).reshape(n, c, hs, ws)
+        if self.downsample:
+            x = ops.interpolate_bilinear(x, (h, w))
         x = self.last_layer(ops.channel_cat([emb, x]))
         preds = torch.split(x, B, dim=0)
         if segSize is None:
@@ -61,8 +64,6 @@ class Non_local3d(LrGroupsMixin, nn.Module):
 class Non_local2d(nn.Module):
     def __init__(self, num_class=None, downsample=False):
         super().__init__()
-        if downsample:
-            raise NotImplementedError("the avg-pool `downsample` switch is not on the HIP path")
         self.downsample = downsample
         self.emb = vnn.Conv2d(2048, 256, 1, 1)
         self.nonlocalblock = NLBlockND(in_channels=256, mode="dot", dimension=2, bn_layer=True)
@@ -70,7 +71,10 @@ class Non_local2d(nn.Module):
 
     def forward(self, input, segSize=None):
         emb = self.emb(input[-1])
-        x = self.nonlocalblock(emb)
+        if self.downsample:  # reference :135-138
+            x = ops.interpolate_bilinear(self.nonlocalblock(ops.avg_pool2x2(emb)), emb.shape[-2:])
+        else:
+            x = self.nonlocalblock(emb)
         pred = self.last_layer(ops.channel_cat([emb, x]))
         if segSize is None:
             return ops.log_softmax_channels(pred)

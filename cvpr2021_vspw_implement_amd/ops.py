@@ -587,7 +587,9 @@ def _all_reduce_sums(sums):
     if tm is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_sync_group["group"])
+    from . import distributed as vdist  # (imports this module: resolved at call time)
+
+    vdist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_sync_group["group"])
     if tm is not None:
         e1.record()
         tm.append((e0, e1))
@@ -1290,6 +1292,32 @@ class BilinearFn(torch.autograd.Function):
 
 def interpolate_bilinear(x, size):
     return BilinearFn.apply(x, tuple(size))
+
+
+class AvgPool2x2Fn(torch.autograd.Function):
+    """F.avg_pool2d(x, (2, 2)): the non-local decoders' `downsample` switch (models/non_local_models.py:30-32,136-137)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require_gpu(x, "avg_pool2x2")
+        x = to_nhwc(x)
+        n, c, h, w = x.shape
+        y = empty_nhwc(n, c, h // 2, w // 2, x.device)
+        _C.call("vspw_avgpool2x2_nhwc_fwd", _p(x), _p(y), n, h, w, c, _stream())
+        ctx.meta = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w = ctx.meta
+        g = to_nhwc(g)
+        dx = empty_nhwc(n, c, h, w, g.device)
+        _C.call("vspw_avgpool2x2_nhwc_bwd", _p(g), _p(dx), n, h, w, c, _stream())
+        return dx
+
+
+def avg_pool2x2(x):
+    return AvgPool2x2Fn.apply(x)
 
 
 # --------------------------------------------------------------------------------------------------- softmax / loss

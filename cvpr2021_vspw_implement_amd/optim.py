@@ -81,7 +81,17 @@ class SGD(torch.optim.Optimizer):
         if len(saved) != len(self.param_groups):
             raise ValueError("loaded state dict has a different number of parameter groups")
         if all("mult" in g for g in saved):
-            return super().load_state_dict(state_dict)
+            # torch rebuilds every param_group from the saved dict (keeping only this optimizer's 'params'): the private
+            # keys computed in __init__ - 'order', which the round-2 layout never stored, and 'mult' - are put back
+            keep = [(g["mult"], g["order"]) for g in self.param_groups]
+            for (mult, _), sg in zip(keep, saved):
+                if list(sg["mult"]) != list(mult):
+                    raise ValueError("loaded state dict lists different parameter multiplicities than this optimizer")
+            super().load_state_dict(state_dict)
+            for g, (mult, order) in zip(self.param_groups, keep):
+                g["mult"], g["order"] = mult, order
+            self._buckets = {}
+            return
         by_index = {}
         for g, sg in zip(self.param_groups, saved):
             expanded = [g["params"][i] for i in g["order"]]

@@ -116,7 +116,10 @@ class GraphedTrainStep(object):
         try:
             self.graph = GraphedStep(step, warmup=2, stream=getattr(args, "_work_stream", None))
         finally:  # also when the capture fails (an RCCL build that cannot be captured): the warm-up steps are undone
-            torch.cuda.synchronize()
+            try:
+                torch.cuda.synchronize()
+            except RuntimeError:  # an invalidated capture can make the sync itself raise: the restore must still run
+                pass
             with torch.no_grad():
                 for k, v in inner.state_dict().items():
                     v.copy_(snap[k])
@@ -213,7 +216,7 @@ def test(segmentation_module, args, transform, log=print, rank=0, world=1):
     if world > 1:
         cm = torch.from_numpy(evaluator.confusion_matrix).to(transform.device if hasattr(transform, "device")
                                                              else "cuda")
-        vdist.dist.all_reduce(cm)
+        vdist.all_reduce(cm)
         evaluator.confusion_matrix = cm.cpu().numpy()
     Acc = evaluator.Pixel_Accuracy()
     Acc_class = evaluator.Pixel_Accuracy_Class()

@@ -255,6 +255,11 @@ int vspw_temporal_mean_bwd(const float* dy, const float* wts, float* dx, int T, 
 int vspw_temporal_mean_wgrad(const float* dy, const float* x, float* dw, int T, int B, long long inner,
                              int accumulate, void* stream);
 
+/* F.avg_pool2d(x, (2,2)) on NHWC activations [n][h][w][c] -> [n][h/2][w/2][c] (stride 2, no padding, floor size) and
+ * its adjoint: the `downsample` switch of the non-local decoders (models/non_local_models.py:30-32,136-137).  c % 4 == 0. */
+int vspw_avgpool2x2_nhwc_fwd(const float* x, float* y, int n, int h, int w, int c, void* stream);
+int vspw_avgpool2x2_nhwc_bwd(const float* dy, float* dx, int n, int h, int w, int c, void* stream);
+
 /* ---------------------------------------------------------------- bilinear (interp.hip) ----------- */
 /* F.interpolate(mode='bilinear', align_corners=False) (models/clip_psp.py:49-52, models/models.py:96,102).
  * Output rows have ldo channels and the result lands at channel offset co (writes straight into the PPM concat).

@@ -341,6 +341,52 @@ def case_nonlocal3d(M, arch, tag, T=3, train_shape=(1, 3, 49, 49)):
     print(tag, "loss %.6f acc %.4f" % (loss.item(), acc.item()))
 
 
+def case_nonlocal_downsample(M, arch, tag, T=3, shape=(2, 3, 73, 73)):
+    """The avg-pool `downsample` switch of both non-local decoders (reference models/non_local_models.py:30-32,43-44,
+    135-138): Non_local3d(downsample=True) over T frames and SegmentationModule(encoder, Non_local2d(downsample=True)).
+    73x73 crops -> 10x10 embedding... (the 2x2 pool halves it to 5x5, bilinear back up)."""
+    from models.non_local_models import Non_local2d  # reference
+
+    res = {}
+    crit = torch.nn.NLLLoss(ignore_index=255)
+    for which in ("3d", "2d"):
+        torch.manual_seed(0)
+        enc = M.ModelBuilder.build_encoder(arch=arch, fc_dim=2048)
+        if which == "3d":
+            mod = M.Non_local3d(args_ns(), enc, crit, downsample=True)
+            imgs = [torch.from_numpy(det_input("%s:3d:%d" % (tag, t), shape)) for t in range(T)]
+            labs = [torch.from_numpy(det_labels("%s:3d:%d" % (tag, t), (shape[0], 1) + shape[2:], K)) for t in range(T)]
+            feed = lambda: {"clipimgs_data": list(imgs), "cliplabels_data": list(labs)}  # noqa: E731
+        else:
+            mod = M.SegmentationModule(enc, Non_local2d(num_class=K, downsample=True), crit, None)
+            img = torch.from_numpy(det_input("%s:2d" % tag, shape))
+            lab = torch.from_numpy(det_labels("%s:2d" % tag, (shape[0], 1) + shape[2:], K))
+            feed = lambda: {"img_data": img, "seg_label": lab}  # noqa: E731
+        load_det(mod)
+        # W_z's BatchNorm gamma is zero-initialised by the reference's constructor; load_det gave it U(0.5,1.5), so the
+        # block contributes
+        for k, v in calibrate_bn(mod, lambda: mod(feed())).items():
+            res["%s:%s" % (which, k)] = v
+        mod.train()
+        mod.zero_grad()
+        loss, acc = mod(feed())
+        loss.backward()
+        res[which + ":train_loss"] = np.float64(loss.item())
+        res[which + ":train_acc"] = np.float64(acc.item())
+        for k, v in grads_summary(mod, full=("encoder.layer4.2.conv3.weight",)).items():
+            res["%s:%s" % (which, k)] = v
+        mod.eval()
+        with torch.no_grad():
+            out = mod(feed(), segSize=shape[2:])
+        preds = out if isinstance(out, (list, tuple)) else [out]
+        res[which + ":eval_probs_sub"] = np.stack([p.numpy()[:, :, ::2, ::2] for p in preds])
+        res[which + ":eval_argmax"] = np.stack([p.numpy().argmax(1) for p in preds]).astype(np.uint8)
+        res[which + ":eval_margin"] = np.stack([top2_margin(p.numpy()) for p in preds])
+        print(tag, which, "loss %.6f acc %.4f" % (loss.item(), acc.item()))
+    res["meta"] = np.array([arch, str(T), str(shape)])
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+
+
 def case_netwarp(M, arch, tag, shape=(2, 3, 65, 65)):
     """NetWarp with the flow network replaced by a fixed synthetic field (the RAFT checkpoint is not in the tree):
     pins FlowCNN, the nearest-resized un-rescaled flow, both flow-warps, the per-channel blends and the loss."""
@@ -878,6 +924,8 @@ def main():
         case_segmodule(M, "resnet50dilated", "nonlocal2d", "r50_nonlocal2d", fc_dim=2048)
     if want("r50_nonlocal3d"):
         case_nonlocal3d(M, "resnet50dilated", "r50_nonlocal3d")
+    if want("r50_nonlocal_downsample"):
+        case_nonlocal_downsample(M, "resnet50dilated", "r50_nonlocal_downsample")
     if want("r50_netwarp"):
         case_netwarp(M, "resnet50dilated", "r50_netwarp")
     if want("r50_netwarp_ocr"):

@@ -9,17 +9,45 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.plumbing]  # plumbing: collected last (tests/conftest.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run(cmd, env, timeout):
+    """Run a bench command under a hard timeout; on expiry the child's whole process group is killed and what it wrote
+    (bench.py's phase log / watchdog stacks on stderr) is returned for the assertion message."""
+    import signal
+
+    p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+        return p.returncode, out, err
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        out, err = p.communicate()
+        return -9, out, "TIMEOUT after %d s\n%s" % (timeout, err)
+
+
 def test_bench_launches_two_ranks_and_reports_once(dev):
-    env = dict(os.environ, VSPW_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # collectives raise after 90 s (gloo timeout), a rank without progress for 100 s dumps its stacks and exits 3
+    # (cvpr2021_vspw_implement_amd/watchdog.py), the whole launch is killed after 150 s
+    env = dict(os.environ, VSPW_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", VSPW_DIST_TIMEOUT_S="90",
+               VSPW_WATCHDOG_S="100")
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--no-cpu-baseline", "--no-host-probe", "--no-kernel-timing"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
+           "--crop", "191", "--no-cpu-baseline", "--no-host-probe", "--no-kernel-timing"]
+    rc, out, err = _run(cmd, env, 150)
+    if rc != 0:  # one retry, with the evidence of the first attempt on record (a warning in the test report)
+        import warnings
+
+        warnings.warn("first attempt of the two-rank bench launch failed (rc %d):\n%s" % (rc, err[-4000:]))
+        rc, out, err = _run(cmd, env, 150)
+    assert rc == 0, err[-4000:]
+    r = type("R", (), {"stdout": out, "stderr": err})()
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 only
     out = json.loads(lines[0])
@@ -30,6 +58,8 @@ def test_bench_launches_two_ranks_and_reports_once(dev):
     assert cfg["execution"] == "eager launches" and "gloo" in cfg["backend"]
     assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] / 1e3)) < 0.05 * out["value"]  # whole-job clips/s
     assert 6.0 < out["last_loss"] < 8.0
+    assert "191x191" in cfg["workload"] and "NOT the metric" in cfg["workload"] and out["e2e_mfma_frac"] is None
+    assert "[rank 0" in r.stderr and "[rank 1" in r.stderr  # the phase log of both ranks
 
 
 def test_bench_refuses_more_ranks_than_devices(dev):
@@ -39,9 +69,8 @@ def test_bench_refuses_more_ranks_than_devices(dev):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None)
     env.pop("VSPW_BENCH_SHARED_GPU", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"], env=env,
-                       cwd=ROOT, capture_output=True, text=True, timeout=300)
-    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr
+    rc, out, err = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1"], env, 120)
+    assert rc != 0 and "GPU(s) are visible" in err
 
 
 def test_bench_reports_collective_diagnostics_with_a_one_rank_rccl_group(dev):
@@ -49,14 +78,14 @@ def test_bench_reports_collective_diagnostics_with_a_one_rank_rccl_group(dev):
     all-reduce) on the one GPU of the box.  `auto` must pick eager launches when a process group is alive (a captured
     step can abort the process through ProcessGroupNCCL's watchdog, bench.py main()), and the line must carry the
     `collectives` diagnostics a real scaling run will be read with."""
-    env = dict(os.environ, VSPW_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, VSPW_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0", VSPW_WATCHDOG_S="100")
     env.pop("WORLD_SIZE", None)
     env.pop("VSPW_BENCH_SHARED_GPU", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
            "--no-host-probe"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    rc, stdout, err = _run(cmd, env, 150)
+    assert rc == 0, err[-4000:]
+    out = json.loads([ln for ln in stdout.splitlines() if ln.startswith("{")][-1])
     assert out["config"]["execution"] == "eager launches" and out["config"]["rccl_ranks"] == 1
     c = out["collectives"]
     assert c["syncbn_exchanges_per_step"] == 224            # 112 BatchNorm layers, forward + backward

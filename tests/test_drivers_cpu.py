@@ -128,3 +128,34 @@ def test_optimizer_checkpoint_layout_is_torchs_with_duplicates_expanded():
     back.load_state_dict(got)  # and torch reads what we write
     assert back.param_groups[1]["lr"] == 0.01
     assert torch.equal(back.state[ps[2]]["momentum_buffer"], ref.state[ps[2]]["momentum_buffer"])
+
+
+def test_optimizer_resumes_from_its_round2_layout_and_can_checkpoint_again():
+    """An `opt_epoch_N.pth` written by this class in round 2 (de-duplicated lists, 'mult', no 'order') loads, and the next
+    state_dict() - what checkpoint() calls at the end of the first resumed epoch - works and speaks torch's layout."""
+    import torch
+
+    from cvpr2021_vspw_implement_amd import optim
+
+    ps = [torch.nn.Parameter(torch.randn(3, 2, 1, 1)), torch.nn.Parameter(torch.randn(4)),
+          torch.nn.Parameter(torch.randn(2, 2))]
+    mk = lambda: [{"params": [ps[0], ps[1], ps[0]], "lr": 0.1, "weight_decay": 1e-4},  # noqa: E731
+                  {"params": [ps[2], ps[2], ps[2]], "lr": 0.01, "weight_decay": 0.0}]
+    bufs = [torch.randn_like(p) for p in ps]
+    round2 = {"state": {0: {"momentum_buffer": bufs[0]}, 1: {"momentum_buffer": bufs[1]}, 2: {"momentum_buffer": bufs[2]}},
+              "param_groups": [{"lr": 0.05, "momentum": 0.9, "weight_decay": 1e-4, "mult": [2, 1], "params": [0, 1]},
+                               {"lr": 0.005, "momentum": 0.9, "weight_decay": 0.0, "mult": [3], "params": [2]}]}
+    ours = optim.SGD(mk(), lr=0.1, momentum=0.9, weight_decay=1e-4)
+    ours.load_state_dict(round2)
+    assert [g["mult"] for g in ours.param_groups] == [[2, 1], [3]]
+    assert [g["order"] for g in ours.param_groups] == [[0, 1, 0], [0, 0, 0]]
+    assert ours.param_groups[0]["lr"] == 0.05 and ours.param_groups[1]["lr"] == 0.005
+    got = ours.state_dict()
+    assert [g["params"] for g in got["param_groups"]] == [[2, 1, 2], [5, 5, 5]]
+    assert set(got["state"]) == {1, 2, 5}
+    assert torch.equal(got["state"][2]["momentum_buffer"], bufs[0]) and torch.equal(got["state"][5]["momentum_buffer"], bufs[2])
+    bad = {"state": {}, "param_groups": [dict(round2["param_groups"][0], mult=[1, 1]), round2["param_groups"][1]]}
+    import pytest
+
+    with pytest.raises(ValueError):
+        optim.SGD(mk(), lr=0.1, momentum=0.9).load_state_dict(bad)

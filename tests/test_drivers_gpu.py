@@ -150,6 +150,7 @@ def test_hip_graph_training_loop_equals_the_eager_loop(dev, tree, tmp_path):
     assert len(m0) == len(m1) and all(np.array_equal(a, b) for a, b in zip(m0, m1))
 
 
+@pytest.mark.plumbing
 def test_two_rank_training_driver(dev, tree, tmp_path):
     """train_clip2.main with WORLD_SIZE = 2 (torch.distributed.run; both ranks share the device over gloo in the
     VSPW_SHARED_GPU_TEST mode - RCCL refuses two ranks on one GPU): DistributedSampler shards, parameter broadcast,
@@ -160,7 +161,8 @@ def test_two_rank_training_driver(dev, tree, tmp_path):
 
     save = str(tmp_path / "ck2r")
     os.makedirs(save)
-    env = dict(os.environ, VSPW_SHARED_GPU_TEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, VSPW_SHARED_GPU_TEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", VSPW_DIST_TIMEOUT_S="90",
+               VSPW_WATCHDOG_S="100")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     here = os.path.dirname(os.path.abspath(__file__))
@@ -172,7 +174,7 @@ def test_two_rank_training_driver(dev, tree, tmp_path):
     s.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(here, "two_rank_train_worker.py"), tree, save]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=200)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert r.stdout.count("Training Done!") == 1 and r.stdout.count("Saving checkpoints...") == 1   # rank 0 only
     assert r.stdout.count("Validation:") == 1 and "mIoU" in r.stdout

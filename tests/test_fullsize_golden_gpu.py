@@ -1,0 +1,201 @@
+"""Every BASELINE.json configuration at ITS OWN size against vectors produced by the REFERENCE itself
+(tests/golden/make_golden_fullsize.py: /root/reference imported in the build container, float32 and float64):
+inference at 480x853 for cfg 1-4, one training step at R101 / T=5 / B=2 / 479x479 for cfg 2, 3, 4, 5a.  No oracle is
+evaluated here: stored arrays only, so the whole file takes seconds per case.
+
+Two weight variants per case (see make_golden_fullsize.py / det_init.damp_residual_gammas):
+  damped  well-conditioned (residual-closing BatchNorm gammas x0.25): the reference's fp32 logits are < 3e-4 from its
+          float64 re-run, and north_star's rule applies AS WRITTEN: |hip - ref32| <= 1e-3 on the logits, arg-max
+          identical wherever the reference's top-2 log-probability gap exceeds 2e-3.
+  raw     He-normal weights, gamma~U(0.5,1.5): 33 random BatchNorm'd residual blocks amplify float32 rounding ~1e4-fold;
+          the reference's own fp32 logits are 1e-3..4e-3 from float64.  Both numbers are printed: the direct
+          |hip - ref32|, and |hip - ref64| held to max(1e-3, 2 x |ref32 - ref64|) (helpers.logit_tol's rule).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import K, build, golden, load_det, zero_dropout
+from oracle.det_init import damp_residual_gammas, det_input, det_labels, det_sample_index
+
+pytestmark = pytest.mark.gpu
+H, W, S = 480, 853, 479
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _module(kind, T):
+    if kind == "r18_ppm":
+        return build("seg", "resnet18dilated", "ppm_deepsup", 512), (lambda m: m.decoder.conv_last_)
+    if kind == "r101_ppm":
+        return build("seg", "resnet101dilated", "ppm_deepsup", 2048), (lambda m: m.decoder.conv_last_)
+    if kind == "r101_nonlocal2d":
+        return (build("seg", "resnet101dilated", "nonlocal2d", 2048, deep_sup_scale=None),
+                (lambda m: m.decoder.last_layer))
+    if kind == "clip_psp":
+        return build(kind, "resnet101dilated", args={"clip_num": T}), (lambda m: m.ppm_conv)
+    return build(kind, "resnet101dilated", args={"clip_num": T}), (lambda m: m.head)
+
+
+def _load(mod, variant, fx=None):
+    """deterministic name-keyed weights (+ the reference-calibrated running statistics of an eval fixture)"""
+    load_det(mod, fx=fx)
+    if variant == "damped":
+        sd = {k: v.clone() for k, v in mod.state_dict().items()}
+        assert damp_residual_gammas(sd)
+        mod.load_state_dict(sd)
+    zero_dropout(mod)
+
+
+def _feed(frames, labels, clip):
+    d = {"img_data": frames[-1], "seg_label": labels[-1]}
+    if clip:
+        d.update(clipimgs_data=list(frames[:-1]), cliplabels_data=list(labels[:-1]))
+    return d
+
+
+EVAL = [("r18_ppm", "cfg1"), ("r101_ppm", "cfg2"), ("clip_psp", "cfg3"), ("clip_ocr", "cfg4")]
+TRAIN = [("r101_ppm", "cfg2"), ("clip_psp", "cfg3"), ("clip_ocr", "cfg4"), ("r101_nonlocal2d", "cfg5a")]
+
+
+@pytest.mark.parametrize("variant", ["damped", "raw"])
+@pytest.mark.parametrize("kind,cfg", EVAL)
+def test_480p_inference_against_reference_vectors(dev, kind, cfg, variant):
+    fx = golden("full_eval_%s_%s_%s" % (cfg, kind, variant))
+    clip = kind in ("clip_psp", "clip_ocr")
+    T = 4 if clip else 1
+    mod, tap = _module(kind, T)
+    _load(mod, variant, fx)
+    mod.to(dev).eval()
+    name = "infer480:" + kind
+    frames = [_t(det_input("%s:%d" % (name, t), (1, 3, H, W)), dev) for t in range(T)]
+    zeros = [torch.zeros(1, 1, H, W, device=dev)] * T
+    from cvpr2021_vspw_implement_amd import ops
+
+    # Without autograd the HIP path is the FOLDED one (conv + eval BatchNorm (+ residual) + ReLU in one launch on weights
+    # with the BatchNorm scale folded in: ops._conv_bn_folded); the unfolded path (conv, then BatchNorm apply) is run too
+    got = {}
+    for folded in (True, False):
+        store = {}
+        hk = tap(mod).register_forward_hook(lambda m, i, o: store.__setitem__("l", o.detach().float().cpu().numpy()))
+        hk1 = mod.encoder.layer1.register_forward_hook(lambda m, i, o: store.__setitem__("l1", o.detach().double().cpu()))
+        ops.set_inference_folding(folded)
+        try:
+            with torch.no_grad():
+                p_ = mod(_feed(frames, zeros, clip), segSize=(H, W))
+        finally:
+            ops.set_inference_folding(True)
+            hk.remove()
+            hk1.remove()
+        got[folded] = (store["l"], p_.float().cpu().numpy(), store["l1"])
+    logits, probs, _ = got[True]
+    unfolded = got[False][0][:, :, ::2, ::2]
+    shallow = float((got[True][2] - got[False][2]).norm() / got[False][2].norm())
+    assert shallow <= 1e-5, shallow  # folded vs unfolded, 10 convolutions deep
+    assert logits.shape == (1, K, 60, 107) and probs.shape == (1, K, H, W)
+    sub = logits[:, :, ::2, ::2]
+    own = float(fx["ref32_vs_ref64_logits_max"])
+    e32 = float(np.abs(sub - fx["logits32_sub"]).max())
+    e64 = float(np.abs(sub.astype(np.float64) - fx["logits64_sub"]).max())
+    ep = float(np.abs(probs[:, :, ::16, ::16] - fx["probs32_sub"]).max())
+    am = probs.argmax(1).astype(np.uint8)
+    flips = am != fx["argmax32"]
+    margin = fx["margin32"].astype(np.float32)
+    if variant == "damped":
+        tol = 1e-3  # north_star, unwidened
+        assert own < 5e-4, own
+        assert e32 <= tol, (e32, tol)
+        assert float(np.abs(unfolded - fx["logits32_sub"]).max()) <= tol
+    else:
+        tol = max(1e-3, 2.0 * own)
+        assert e64 <= tol, (e64, tol)
+        assert float(np.abs(unfolded.astype(np.float64) - fx["logits64_sub"]).max()) <= tol
+    decisive = margin > 2 * tol
+    print("%s %s 480x853 vs the reference: |logit| max %.2f; |ref32 - ref64| %.2e; |hip - ref32| %.2e; |hip - ref64| %.2e "
+          "(tol %.1e); probs %.2e; arg-max: %d of %d pixels differ (reference fp32 vs its own fp64: %d), %d decisive"
+          % (cfg, variant, float(fx["logits_absmax"]), own, e32, e64, tol, ep, flips.sum(), flips.size,
+             (fx["argmax32"] != fx["argmax64"]).sum(), (flips & decisive).sum()))
+    assert ep <= 1e-3, ep
+    assert np.abs(probs.sum(1) - 1).max() < 1e-5
+    assert (flips & decisive).sum() == 0
+    if variant == "damped":  # no more disagreement with the reference's fp32 masks than 4x its own fp32-vs-fp64 count
+        assert flips.sum() <= 4 * max(int((fx["argmax32"] != fx["argmax64"]).sum()), 25), flips.sum()
+
+
+@pytest.mark.parametrize("variant", ["damped", "raw"])
+@pytest.mark.parametrize("kind,cfg", TRAIN)
+def test_479_training_step_against_reference_vectors(dev, kind, cfg, variant):
+    """loss / accuracy / train-mode logits / BatchNorm running statistics / every parameter's gradient (norm + 256 fixed
+    elements) of one step.  ReLU and max-pool decisions are free on both sides, so the gradient gate is relative to the
+    reference's OWN float32-vs-float64 distance on the same statistic (factor 2: one rounding realisation differs from
+    the next by up to 1.5x), with an absolute floor of 1e-3."""
+    fx = golden("full_train_%s_%s_%s" % (cfg, kind, variant))
+    clip = kind in ("clip_psp", "clip_ocr")
+    T = 5 if clip else 1
+    B = 2
+    mod, tap = _module(kind, T)
+    _load(mod, variant)
+    mod.to(dev).train()
+    name = "train479:" + kind
+    frames = [_t(det_input("%s:%d" % (name, t), (B, 3, S, S)), dev) for t in range(T)]
+    labels = [_t(det_labels("%s:%d" % (name, t), (B, 1, S, S), K), dev) for t in range(T)]
+    store = {}
+    hk = tap(mod).register_forward_hook(lambda m, i, o: store.__setitem__("l", o.detach().float().cpu().numpy()))
+    loss, acc = mod(_feed(frames, labels, clip))
+    hk.remove()
+    loss.backward()
+    torch.cuda.synchronize()
+    l32, l64 = float(fx["loss32"]), float(fx["loss64"])
+    lh = loss.item()
+    own_loss = abs(l32 - l64) / abs(l64)
+    assert abs(lh - l64) <= max(2e-5, 2 * own_loss) * abs(l64), (lh, l32, l64)
+    assert abs(acc.item() - float(fx["acc64"])) <= max(1e-3, 2 * abs(float(fx["acc32"]) - float(fx["acc64"])))
+    # train-mode logits of the head
+    sub = store["l"][:, :, ::2, ::2]
+    own_l = float(np.abs(fx["logits32_sub"] - fx["logits64_sub"]).max())
+    e_l32 = float(np.abs(sub - fx["logits32_sub"]).max())
+    e_l64 = float(np.abs(sub - fx["logits64_sub"]).max())
+    assert e_l64 <= max(1e-3, 2 * own_l), (e_l64, own_l)
+    if own_l < 5e-4:
+        assert e_l32 <= 1e-3, e_l32  # north_star as written
+    # running statistics after the step (momentum 0.1, unbiased variance)
+    mods = dict(mod.named_modules())
+    for key in fx.files:
+        if key.startswith("running_mean:") or key.startswith("running_var:"):
+            what, bn = key.split(":")
+            got = getattr(mods[bn], what).detach().cpu().numpy()
+            assert np.abs(got - fx[key]).max() <= 1e-4 * max(1.0, np.abs(fx[key]).max()), key
+    # gradients
+    names = [str(n) for n in fx["grad_names"]]
+    grads = {k: p.grad for k, p in mod.named_parameters() if p.grad is not None}
+    assert set(names) == set(grads), sorted(set(names) ^ set(grads))[:5]
+    n32, n64 = fx["grad_norms32"], fx["grad_norms64"]
+    scale = float(n64.max())
+    nh = np.array([float(grads[k].double().norm()) for k in names])
+    den = np.maximum(n64, 1e-3 * scale)
+    rel_h, rel_o = np.abs(nh - n64) / den, np.abs(n32 - n64) / den
+    # sampled elements: per-parameter relative L2 over the 256 fixed positions
+    s32, s64 = fx["grad_samples32"].astype(np.float64), fx["grad_samples64"]
+    sh, off = [], 0
+    es_h, es_o = [], []
+    for k in names:
+        g = grads[k].detach().contiguous().view(-1)
+        idx = det_sample_index(k, g.numel())
+        v = g[_t(idx, dev)].double().cpu().numpy()
+        r64, r32 = s64[off:off + len(idx)], s32[off:off + len(idx)]
+        off += len(idx)
+        floor = 1e-3 * scale * (len(idx) / g.numel()) ** 0.5  # the sample's share of a norm at 1e-3 of the largest
+        d = max(float(np.linalg.norm(r64)), floor)
+        es_h.append(float(np.linalg.norm(v - r64)) / d)
+        es_o.append(float(np.linalg.norm(r32 - r64)) / d)
+    es_h, es_o = np.array(es_h), np.array(es_o)
+    st = lambda v: "median %.2e p99 %.2e max %.2e" % (np.median(v), np.percentile(v, 99), v.max())  # noqa: E731
+    print("%s %s 479x479 step vs the reference: loss hip %.7f ref32 %.7f ref64 %.7f; logits |hip-ref32| %.2e |hip-ref64| "
+          "%.2e (|ref32-ref64| %.2e)\n  grad norms, rel. to ref64:   HIP %s | reference fp32 %s\n  grad samples, rel. L2:       "
+          "HIP %s | reference fp32 %s"
+          % (cfg, variant, lh, l32, l64, e_l32, e_l64, own_l, st(rel_h), st(rel_o), st(es_h), st(es_o)))
+    for what, f in (("median", np.median), ("p99", lambda v: np.percentile(v, 99)), ("max", np.max)):
+        assert f(rel_h) <= max(1e-3, 2.0 * f(rel_o)), ("norms", what, f(rel_h), f(rel_o))
+        assert f(es_h) <= max(1e-3, 2.0 * f(es_o)), ("samples", what, f(es_h), f(es_o))

@@ -287,6 +287,7 @@ def _errors(get, ref, names, scale):
     return out
 
 
+@pytest.mark.live_oracle
 def test_bench_workload_gradients_with_pinned_decisions(bench_case):
     """Question (1) above.  Loss of each HIP step within 2e-5 relative of its decision-injected float64 run."""
     c, kind = bench_case, bench_case["kind"]
@@ -323,6 +324,7 @@ def test_bench_workload_gradients_with_pinned_decisions(bench_case):
         assert f(rep_h) <= max(1e-3, 1.5 * f(rep_o)), ("reproducible", what, f(rep_h), f(rep_o))
 
 
+@pytest.mark.live_oracle
 def test_bench_workload_against_fp32_ensemble(bench_case):
     """Question (2) above.  Free comparison (every implementation takes its own decisions) against the float64 oracle:
     loss 2e-4 relative, pixel accuracy 2e-3; per-parameter gradient-norm error - RMS, maximum, and the relative error of

@@ -29,6 +29,7 @@ def _t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
+@pytest.mark.live_oracle
 @pytest.mark.parametrize("kind", ["seg_ppm", "clip_psp", "clip_ocr"])
 def test_480p_inference_values_through_the_folded_path(dev, kind, tmp_path):
     from cvpr2021_vspw_implement_amd import ops

@@ -643,3 +643,24 @@ def test_non_local_dot_fused(dev, B, N, C):
     # bit-reproducible: fixed summation order, no atomics
     yd2 = ops.non_local_dot(dl[0], dl[1], dl[2], 1.0 / N)
     assert torch.equal(yd, yd2)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 10, 10), (3, 256, 9, 13), (1, 4, 2, 2)])
+def test_avg_pool2x2_matches_aten_semantics(dev, shape):
+    """F.avg_pool2d(x, (2, 2)) (models/non_local_models.py:32,136): floor output size (odd trailing row / column dropped),
+    forward bit-exact against the window sum in ATen's order / 4, adjoint = dy / 4 scattered to the four taps."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(n, c, h, w, generator=g)
+    dy = torch.randn(n, c, h // 2, w // 2, generator=g)
+    xd = x.to(dev).requires_grad_(True)
+    y = ops.avg_pool2x2(xd)
+    y.backward(dy.to(dev))
+    xe = x[:, :, :h // 2 * 2, :w // 2 * 2]
+    want = (((xe[:, :, 0::2, 0::2] + xe[:, :, 0::2, 1::2]) + xe[:, :, 1::2, 0::2]) + xe[:, :, 1::2, 1::2]) * 0.25
+    assert torch.equal(y.detach().cpu().contiguous(), want)
+    dx = torch.zeros_like(x)
+    dx[:, :, :h // 2 * 2, :w // 2 * 2] = (dy * 0.25).repeat_interleave(2, 2).repeat_interleave(2, 3)
+    assert torch.equal(xd.grad.cpu().contiguous(), dx)

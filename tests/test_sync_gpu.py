@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.plumbing]  # plumbing: collected last (tests/conftest.py)
 
 
 def _free_port():
@@ -41,20 +41,27 @@ def _data():
 def _worker(rank, world, port, q, backend="gloo"):
     local = rank if backend == "nccl" else 0
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(local), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      LOCAL_RANK=str(local), HSA_ENABLE_IPC_MODE_LEGACY="0", VSPW_DIST_TIMEOUT_S="90")
+    if backend == "gloo":
+        os.environ["VSPW_SHARED_GPU_TEST"] = "1"  # host-staged collectives (distributed.all_reduce)
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
     sys.path.insert(0, os.path.dirname(here))
     from cvpr2021_vspw_implement_amd import distributed as vdist
+    from cvpr2021_vspw_implement_amd import watchdog
 
+    wd = watchdog.make(True, 100.0)
+    wd.phase("init process group")
     vdist.init_from_env(backend=backend)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(local)
+    wd.phase("build + broadcast")
     mod = _build(dev)
     wrapped = vdist.DataParallelOverRCCL(mod, bucket_mb=4.0, sync_bn=True)
     img, lab = _data()
+    wd.phase("forward + backward + gradient averaging")
     sl = slice(rank * 2, rank * 2 + 2)
     loss, acc = wrapped({"img_data": torch.from_numpy(img[sl]).to(dev), "seg_label": torch.from_numpy(lab[sl]).to(dev)})
     loss.backward()
@@ -64,8 +71,11 @@ def _worker(rank, world, port, q, backend="gloo"):
            "grads": {k: p.grad.double().norm().item() for k, p in mod.named_parameters() if p.grad is not None},
            "rm": mod.encoder.layer3[0].bn1.running_mean.cpu().numpy(),
            "rv": mod.encoder.layer3[0].bn1.running_var.cpu().numpy()}
+    wd.phase("report + destroy process group")
     q.put((rank, out))
     torch.distributed.destroy_process_group()
+    wd.phase("exit")
+    wd.stop()
 
 
 def test_two_ranks_equal_one_full_batch(dev):
@@ -85,9 +95,9 @@ def _two_ranks(dev, backend):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=600) for _ in range(2))
+    res = dict(q.get(timeout=150) for _ in range(2))
     for p in procs:
-        p.join(120)
+        p.join(60)
         assert p.exitcode == 0
     # single process, full batch (no labels ignored, so mean-of-rank-means == full-batch mean)
     from cvpr2021_vspw_implement_amd import ops

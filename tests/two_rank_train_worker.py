@@ -12,6 +12,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main(tree, save):
+    from cvpr2021_vspw_implement_amd import watchdog
+
+    wd = watchdog.make(True, 100.0)  # a rank without progress for 100 s dumps its stacks and exits 3
+    wd.phase("import + train_clip2.main (2 epochs on the tiny tree)", 150)
     import cvpr2021_vspw_implement_amd.train_clip2 as T
     from cvpr2021_vspw_implement_amd.config import cfg as base_cfg
 
@@ -33,12 +37,14 @@ def main(tree, save):
 
     T.build_module = build_and_keep
     hist = T.main(cfg, [0, 1], args)
+    wd.phase("digest")
     rank = int(os.environ["RANK"])
     sd = captured["module"].state_dict()
     digest = np.array([float(v.double().sum().item()) for k, v in sorted(sd.items())]
                       + [float(v.double().abs().sum().item()) for k, v in sorted(sd.items())])
     np.save(os.path.join(save, "rank%d_digest.npy" % rank), digest)
     np.save(os.path.join(save, "rank%d_loss.npy" % rank), np.array(hist["train"]["loss"]))
+    wd.stop()
 
 
 if __name__ == "__main__":

@@ -116,9 +116,16 @@ def check(rc: int, what: str):
         raise RuntimeError("%s failed: %s%s" % (what, _ERR.get(rc, str(rc)), detail))
 
 
+trace = None  # optional callable(name, args) -> context manager (ops.kernel_timer: HIP events around HBM-bound kernels)
+
+
 def call(name: str, *args):
     """Call an int-returning entry point and raise on a non-zero status."""
-    rc = getattr(load(), name)(*args)
+    if trace is not None:
+        with trace(name, args):
+            rc = getattr(load(), name)(*args)
+    else:
+        rc = getattr(load(), name)(*args)
     if rc != 0:
         check(rc, name)
 

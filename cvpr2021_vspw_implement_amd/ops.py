@@ -72,17 +72,86 @@ def _conv_desc(x, k, kh, kw, stride, pad, dil):
 
 # Optional per-launch timing of the MFMA GEMM kernels (bench.py's roofline leg): HIP events are recorded on the
 # stream the kernels are launched on (torch's current stream) around every igemm launch.
-_ktimer = {"on": False, "records": []}
+_ktimer = {"on": False, "records": [], "hbm": []}
 
 
 def kernel_timer(enable, reset=True):
     _ktimer["on"] = bool(enable)
+    _C.trace = _hbm_trace if enable else None
     if enable and reset:
         _ktimer["records"] = []
+        _ktimer["hbm"] = []
 
 
 def kernel_timer_reset():
     _ktimer["records"] = []
+    _ktimer["hbm"] = []
+
+
+# HBM-bound kernel families timed next to the GEMMs (bench.py's roofline_hbm): entry point -> ALGORITHMIC bytes of one
+# launch from its arguments = every operand stream read once + every result written once (per-channel vectors ignored).
+def _nn(*ptrs):
+    return sum(1 for q in ptrs if q is not None)
+
+
+def _wino_bytes(a, chan_idx, streams_full, m_idx=None):
+    d = a[0]._obj
+    T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
+    c = int(a[chan_idx])
+    return 4.0 * c * (16.0 * T + d.n * d.h * d.w * streams_full)
+
+
+_HBM_BYTES = {
+    # x [, residual] -> z
+    "vspw_bn_apply": lambda a: 4.0 * a[6] * a[7] * (2 + _nn(a[3])),
+    # dz, z?, x -> dx [, dres]
+    "vspw_bn_bwd_apply": lambda a: 4.0 * a[9] * a[10] * _nn(a[0], a[1], a[2], a[14], a[15]),
+    "vspw_bn_bwd_reduce_pg": lambda a: 4.0 * a[6] * a[7] * _nn(a[0], a[1], a[2]),
+    "vspw_bn_stats": lambda a: 4.0 * a[1] * a[2],
+    "vspw_wino_input": lambda a: _wino_bytes(a, 2, 1),
+    "vspw_wino_dy": lambda a: _wino_bytes(a, 2, 1),
+    # M -> y (+ relu_src / bn_y / addend operand streams when present)
+    "vspw_wino_output": lambda a: _wino_bytes(a, 2, 1 + _nn(a[5], a[6], a[10])),
+}
+
+
+class _HbmTimed:
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes = name, nbytes
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e1 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def __exit__(self, *a):
+        self.e1.record()
+        _ktimer["hbm"].append((self.name, self.nbytes, self.e0, self.e1))
+        return False
+
+
+class _NoTrace:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NO_TRACE = _NoTrace()
+
+
+def _hbm_trace(name, args):
+    f = _HBM_BYTES.get(name)
+    if f is None or torch.cuda.is_current_stream_capturing():
+        return _NO_TRACE
+    return _HbmTimed(name, float(f(args)))
+
+
+def hbm_timer_records():
+    """[(entry point, algorithmic bytes, ms)] of every timed launch of the HBM-bound families (synchronises)."""
+    torch.cuda.synchronize()
+    return [(n, b, e0.elapsed_time(e1)) for n, b, e0, e1 in _ktimer.get("hbm", [])]
 
 
 def kernel_timer_records():

@@ -372,6 +372,7 @@ def main():
     model.reducer.timer = None
     wd.phase("max-over-ranks timing")
     last_loss = float(loss.item())
+    model.check_exchange()  # a peer statistics exchange that timed out poisons the step with NaN: fail loudly
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         vdist.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -452,6 +453,8 @@ def main():
                 "allreduce_exposed_ms_per_step": round(sum(a.elapsed_time(b) for a, b in red_events.get("wait", [])) / nst, 3),
                 "allreduce_launch_to_done_ms_max": round(max([a.elapsed_time(b) for a, b in red_events.get("buckets", [])]
                                                             or [0.0]), 3),
+                "syncbn_exchange": ("peer exchange (hipIpc arenas, one kernel per exchange: csrc/exchange.hip)"
+                                    if getattr(model, "exchange", None) is not None else "torch.distributed all-reduce"),
                 "rccl_graph_capture": rccl_capture, "sync_bn": not args.no_sync_bn,
                 "sync_bn_formula": "clamp(var,eps)" if args.sync_bn_clamp_var else "var+eps"}
 

@@ -143,11 +143,26 @@ class GradReducer:
                 self.hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def broadcast_parameters(self, module, src=0):
+        """Rank `src`'s parameters and buffers to every rank (the reference's DataParallel re-broadcasts the replicas
+        every step, train_clip2.py:359-364; one process per GPU needs it once).  ONE broadcast per dtype over a
+        flattened copy instead of ~1 300 tiny ones: a start-up of milliseconds over RCCL, and no per-message latency
+        (40 ms delayed-ACK stalls were measured per small gloo message in the shared-GPU test mode: a minute in total)."""
         if not self.active:
             return
+        by_dtype = {}
+        seen = set()
         for t in list(module.parameters()) + list(module.buffers()):
-            if t.is_floating_point() or t.dtype == torch.long:
-                broadcast(t.data, src=src, group=self.group)
+            if (t.is_floating_point() or t.dtype == torch.long) and id(t) not in seen:
+                seen.add(id(t))
+                by_dtype.setdefault((t.dtype, t.device), []).append(t.data)
+        for ts in by_dtype.values():
+            flat = torch.cat([t.reshape(-1) for t in ts])  # reshape(-1): a copy in logical order for channels_last weights
+            broadcast(flat, src=src, group=self.group)
+            off = 0
+            for t in ts:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view(t.shape))
+                off += n
 
     def _launch(self, bi):
         """Gather the bucket's gradients into its flat buffer with ONE multi-tensor copy, then start the all-reduce."""
@@ -233,10 +248,24 @@ class DataParallelOverRCCL(torch.nn.Module):
         self.reducer = GradReducer(module, bucket_mb, force=force_collectives,
                                    find_unused_parameters=find_unused_parameters)
         self.reducer.broadcast_parameters(module)
-        ops.set_sync_bn(sync_bn and self.reducer.active, force=force_collectives, clamp_var=sync_bn_clamp_var)
+        # SyncBN statistics: hipIpc peer exchange (peer_exchange.py) when every rank of the group could set it up and
+        # its self-test passed everywhere, torch.distributed all-reduces otherwise (VSPW_SYNCBN_PEER=0: always)
+        self.exchange = None
+        if sync_bn and self.reducer.active and torch.cuda.is_available() and os.environ.get("VSPW_SYNCBN_PEER", "1") == "1":
+            from .peer_exchange import PeerExchange
+
+            xc = PeerExchange()
+            self.exchange = xc if xc.ok else None
+        ops.set_sync_bn(sync_bn and self.reducer.active, force=force_collectives, clamp_var=sync_bn_clamp_var,
+                        exchange=self.exchange)
 
     def forward(self, *a, **k):
         return self.module(*a, **k)
 
     def finish_gradients(self):
         self.reducer.wait()
+
+    def check_exchange(self):
+        """Raise if a peer statistics exchange timed out (device sync: call where the loss is read anyway)."""
+        if self.exchange is not None:
+            self.exchange.check()

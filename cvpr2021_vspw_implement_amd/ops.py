@@ -612,13 +612,13 @@ def conv2d(x, w, bias=None, stride=1, pad=0, dil=1):
 
 
 # --------------------------------------------------------------------------------------------------- batch norm
-_sync_group = {"enabled": False, "group": None, "force": False, "clamp_var": False, "timer": None}
+_sync_group = {"enabled": False, "group": None, "force": False, "clamp_var": False, "timer": None, "exchange": None}
 # populations up to this many rows take their statistics two-pass in fp64 from the activations (see bn.hip:
 # bn_small_finalize_kernel) instead of from the convolution epilogue's fp32 tile partials
 _BN_SMALL_ROWS = 1024
 
 
-def set_sync_bn(enabled, group=None, force=False, clamp_var=False):
+def set_sync_bn(enabled, group=None, force=False, clamp_var=False, exchange=None):
     """Enable the cross-rank exchange of BatchNorm statistics (SynchronizedBatchNorm semantics,
     models/sync_batchnorm/batchnorm.py:110-150) over torch.distributed (RCCL on ROCm).
     `force` issues the collectives even in a 1-rank group (exercises the RCCL path on a single-GPU box).
@@ -629,6 +629,8 @@ def set_sync_bn(enabled, group=None, force=False, clamp_var=False):
     _sync_group["group"] = group
     _sync_group["force"] = bool(force)
     _sync_group["clamp_var"] = bool(clamp_var)
+    # peer_exchange.PeerExchange (hipIpc arenas + one small kernel per exchange) or None = torch.distributed all-reduce
+    _sync_group["exchange"] = exchange if enabled else None
 
 
 def sync_bn_timer(store):
@@ -656,12 +658,38 @@ def _all_reduce_sums(sums):
     if tm is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    from . import distributed as vdist  # (imports this module: resolved at call time)
+    xc = _sync_group["exchange"]
+    if xc is not None and xc.usable(sums):
+        xc.all_reduce(sums)
+    else:
+        from . import distributed as vdist  # (imports this module: resolved at call time)
 
-    vdist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_sync_group["group"])
+        vdist.all_reduce(sums, op=dist.ReduceOp.SUM, group=_sync_group["group"])
     if tm is not None:
         e1.record()
         tm.append((e0, e1))
+
+
+def _sync_finalize(sums, world, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                   c, st):
+    """sums [2][c] (this rank's) -> cross-rank totals (world != 1) -> mean / invstd / scale / shift + running statistics.
+    With the peer exchange the all-reduce and the finalisation are ONE launch (vspw_xchg_bn_finalize)."""
+    xc = _sync_group["exchange"] if world != 1 else None
+    if xc is not None and xc.usable(sums):
+        tm = _sync_group["timer"]
+        if tm is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        xc.bn_finalize(sums, c, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                       _sync_group["clamp_var"])
+        if tm is not None:
+            e1.record()
+            tm.append((e0, e1))
+        return
+    if world != 1:
+        _all_reduce_sums(sums)
+    _C.call(_finalize_name() if world != 1 else "vspw_bn_finalize", _p(sums), ctypes.c_double(count), _p(gamma), _p(beta),
+            _p(running_mean), _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), c, st)
 
 
 def _finalize_name():
@@ -719,11 +747,9 @@ class BatchNormActFn(torch.autograd.Function):
                     ws = _ws(nbytes, dev)
                     _C.call("vspw_bn_stats", _p(x), rows, c, _p(sums), _p(ws), nbytes, st)
                 if world != 1:
-                    _all_reduce_sums(sums)
                     count = float(rows * max(world, 1))
-                _C.call(_finalize_name() if world != 1 else "vspw_bn_finalize", _p(sums), ctypes.c_double(count),
-                        _p(gamma), _p(beta), _p(running_mean),
-                        _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), c, st)
+                _sync_finalize(sums, world, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                               scale, shift, c, st)
         else:
             _C.call("vspw_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(mean),
                     _p(invstd), _p(scale), _p(shift), c, st)
@@ -926,11 +952,9 @@ class ConvBNActFn(torch.autograd.Function):
                     ws = _ws(nbytes, dev)
                     _C.call("vspw_bn_stats", _p(y), rows, c, _p(sums), _p(ws), nbytes, st)
                 if world != 1:
-                    _all_reduce_sums(sums)
                     count = float(rows * max(world, 1))
-                _C.call(_finalize_name() if world != 1 else "vspw_bn_finalize", _p(sums), ctypes.c_double(count),
-                        _p(gamma), _p(beta), _p(running_mean),
-                        _p(running_var), momentum, eps, _p(mean), _p(invstd), _p(scale), _p(shift), c, st)
+                _sync_finalize(sums, world, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                               scale, shift, c, st)
         else:
             _C.call("vspw_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(mean),
                     _p(invstd), _p(scale), _p(shift), c, st)

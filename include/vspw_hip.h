@@ -423,6 +423,35 @@ size_t vspw_nl_dot_workspace(int b, int n, int c);
 int vspw_nl_dot(const float* q, const float* k, const float* v, float* out, int b, int n, int c, float scale, void* ws,
                 size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------- peer statistics exchange (exchange.hip) --- */
+/* The cross-replica sum of SynchronizedBatchNorm (models/sync_batchnorm/batchnorm.py:110-131, comm.py:59-137: the
+ * master replica collects [sum, ssum, count] of every device and hands the totals back) for one process per GPU: every
+ * rank owns an arena in its HBM which all peers map through hipIpc; one single-workgroup kernel per exchange pushes
+ * the rank's 2*C doubles into every arena, publishes a sequence number, waits for the others' and adds the `world`
+ * contributions in rank order (bit-identical totals on every rank).  See csrc/exchange.hip for the protocol.
+ *   vspw_xchg_arena_bytes   size of one arena for `world` ranks (<= 16) and messages of up to slot_doubles doubles
+ *   vspw_xchg_alloc         allocate + zero this rank's arena (uncached device memory), export its IPC handle
+ *                           (vspw_xchg_handle_bytes() bytes of HOST memory); synchronous, start-up only
+ *   vspw_xchg_open / close  map / unmap a peer's arena from its handle;  vspw_xchg_free: release the own arena
+ *   vspw_xchg_allreduce_f64 in-place sum of data[0..n) over the ranks; arenas: HOST array of `world` device pointers
+ *                           (own arena at [rank]); counter: device uint64 (zero at start-up, advanced by the kernel:
+ *                           hipGraph replays stay in sequence); status: device int, 1 after a wait exceeded timeout_s
+ *                           (the result is then NaN - a dead peer never hangs the GPU). */
+size_t vspw_xchg_arena_bytes(int world, int slot_doubles);
+int vspw_xchg_handle_bytes(void);
+int vspw_xchg_alloc(size_t bytes, void** arena, void* handle_out);
+int vspw_xchg_open(const void* handle, void** arena);
+int vspw_xchg_close(void* arena);
+int vspw_xchg_free(void* arena);
+int vspw_xchg_allreduce_f64(double* data, int n, void* const* arenas, int world, int rank, unsigned long long* counter,
+                            int slot_doubles, double timeout_s, int* status, void* stream);
+/* The exchange of sums [2][c] and the vspw_bn_finalize / vspw_bn_finalize_clamped (clamp_var) that consumes the totals,
+ * in one launch (batchnorm.py:110-150); count = rows behind the totals over all ranks. */
+int vspw_xchg_bn_finalize(double* sums, int c, void* const* arenas, int world, int rank, unsigned long long* counter,
+                          int slot_doubles, double timeout_s, int* status, double count, const float* gamma,
+                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                          float* mean, float* invstd, float* scale, float* shift, int clamp_var, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

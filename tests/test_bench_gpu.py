@@ -89,7 +89,8 @@ def test_bench_reports_collective_diagnostics_with_a_one_rank_rccl_group(dev):
     assert out["config"]["execution"] == "eager launches" and out["config"]["rccl_ranks"] == 1
     c = out["collectives"]
     assert c["syncbn_exchanges_per_step"] == 224            # 112 BatchNorm layers, forward + backward
-    assert 0.5 < c["syncbn_exchange_ms_per_step"] < 50.0
+    assert "peer exchange" in c["syncbn_exchange"]          # hipIpc arenas + one kernel per exchange, self-tested
+    assert 0.2 < c["syncbn_exchange_ms_per_step"] < 50.0
     assert c["grad_buckets"] >= 8 and c["allreduce_exposed_ms_per_step"] >= 0.0
     assert c["rccl_graph_capture"] is None and c["sync_bn"] is True and c["sync_bn_formula"] == "var+eps"
     assert out["roofline"]["effective_direct_conv_tflops"] > out["roofline"]["achieved"]  # Winograd launches counted

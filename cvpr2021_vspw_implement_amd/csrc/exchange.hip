@@ -3,93 +3,121 @@
 // SynchronizedBatchNorm semantics (reference models/sync_batchnorm/batchnorm.py:110-131, comm.py: the master thread
 // collects [sum x, sum x^2, count] from every replica and hands the totals back) need one small all-reduce per BatchNorm
 // layer and direction - 224 per TCB-PSP step, each 2*C doubles (<= 32 KB), each on the critical path.  A general
-// collective library pays a launch + a ring protocol per call (measured: 17 us per RCCL all-reduce with ONE rank);
-// here every rank owns an ARENA in its own HBM that all peers have mapped (hipIpc), and one single-workgroup kernel does
-//   1. push   : write my 2*C doubles into slot (seq % SLOTS), source = my rank, of EVERY rank's arena (posted writes);
-//   2. publish: system-scope fence, then store seq into the matching flag word of every arena;
-//   3. wait   : spin on the W flag words of MY OWN arena (local memory) until all sources have published seq;
-//   4. sum    : add the W contributions in rank order (same order on every rank: bit-identical totals everywhere).
+// collective library pays a launch + a protocol per call; here every rank owns an ARENA in its own HBM that all peers
+// have mapped (hipIpc), and one single-workgroup kernel per exchange does
+//   1. push: write my values into slot (seq % SLOTS), source = my rank, of EVERY rank's arena (posted writes over
+//            xGMI).  Each double travels as two 8-byte words {32 data bits | 32-bit sequence tag}: an 8-byte store is
+//            atomic, so a word whose tag equals the current sequence number IS valid data - no separate flag, no fence,
+//            no acknowledgement round trip (the "LL" idea of collective libraries);
+//   2. pull: spin on the words of MY OWN arena (local memory) until every source's words carry the tag, and add the W
+//            contributions in rank order (same order on every rank: bit-identical totals everywhere).
 // seq lives in device memory and is advanced by the kernel itself, so a captured hipGraph replays correctly.
-// Slot reuse: a rank can finish exchange k+1 only after every peer has PUBLISHED k+1, i.e. has finished reading k; so a
-// writer is never more than two exchanges ahead of a reader and 4 slots are enough.
+// Slot reuse: a rank can finish exchange k only after every peer has pushed k, i.e. has finished k-1 entirely; a writer
+// is therefore less than two exchanges ahead of any reader and 4 slots are more than enough (tags are compared for
+// EQUALITY, so whatever an older exchange left in a slot never matches).
 // A peer that never arrives (crashed process) ends the wait after `timeout_ticks` of the 100 MHz wall clock: the
 // status word is set, the result is poisoned with NaN and the kernel returns - the GPU never hangs on a dead peer.
+// Every arena access is a system-scope relaxed atomic (write-through stores, cache-missing loads): nothing of an
+// arena ever sits in an L2, so no cache maintenance (and no write-back of a GEMM's dirty output lines) is involved.
 //
-// Arena layout: [SLOTS][world] uint64 flags (rounded up to 4 KB) | [SLOTS][world][slot_doubles] doubles.
+// Arena layout: [SLOTS][world][2 * slot_doubles] 8-byte words.
 #include <string.h>
 
 #include "common.h"
 
 #define XCHG_SLOTS 4
 #define XCHG_MAX_WORLD 16
-#define XCHG_FLAG_BYTES 4096
+#define XCHG_THREADS 1024
+#define XCHG_PER_LANE 8  // slot_doubles <= XCHG_THREADS * XCHG_PER_LANE
+#define XCHG_ST(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+#define XCHG_LD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+
+typedef unsigned long long u64;
 
 struct XchgPeers {
     char* arena[XCHG_MAX_WORLD];
 };
 
-__device__ __forceinline__ unsigned long long* xchg_flag(char* arena, int slot, int world, int src) {
-    return reinterpret_cast<unsigned long long*>(arena) + (size_t)slot * world + src;
-}
-__device__ __forceinline__ double* xchg_box(char* arena, int slot, int world, int src, int slot_doubles) {
-    return reinterpret_cast<double*>(arena + XCHG_FLAG_BYTES) + ((size_t)slot * world + src) * slot_doubles;
+__device__ __forceinline__ u64* xchg_box(char* arena, int slot, int world, int src, int slot_doubles) {
+    return reinterpret_cast<u64*>(arena) + ((size_t)slot * world + src) * (2 * (size_t)slot_doubles);
 }
 
 __device__ __forceinline__ void xchg_allreduce_body(double* __restrict__ data, int n, const XchgPeers& peers, int world,
-                                                    int rank, unsigned long long* __restrict__ counter,
-                                                    int slot_doubles, long long timeout_ticks,
-                                                    int* __restrict__ status) {
+                                                    int rank, u64* __restrict__ counter, int slot_doubles,
+                                                    long long timeout_ticks, int* __restrict__ status) {
     __shared__ int timed_out;
     const int tid = threadIdx.x;
-    const unsigned long long seq = *counter + 1;  // flags start at 0: the first exchange publishes 1
+    const u64 seq = *counter + 1;
     const int slot = (int)(seq % XCHG_SLOTS);
+    const u64 tag = (seq & 0xffffffffULL) << 32;  // arenas are zeroed and seq starts at 1: a fresh word never matches
     if (tid == 0) timed_out = 0;
-    // 1. push
-    for (int w = 0; w < world; ++w) {
-        double* dst = xchg_box(peers.arena[w], slot, world, rank, slot_doubles);
-        for (int i = tid; i < n; i += blockDim.x)
-            __hip_atomic_store(dst + i, data[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    __threadfence_system();
     __syncthreads();
-    // 2. publish
-    if (tid < world)
-        __hip_atomic_store(xchg_flag(peers.arena[tid], slot, world, rank), seq, __ATOMIC_RELEASE,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    // 3. wait
-    if (tid < world) {
-        const unsigned long long* f = xchg_flag(peers.arena[rank], slot, world, tid);
-        const long long t0 = wall_clock64();
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-            if (wall_clock64() - t0 > timeout_ticks) {
-                timed_out = 1;
-                break;
+    // 1. push
+    for (int i = tid; i < n; i += XCHG_THREADS) {
+        const u64 bits = (u64)__double_as_longlong(data[i]);
+        const u64 w0 = tag | (bits & 0xffffffffULL), w1 = tag | (bits >> 32);
+        for (int w = 0; w < world; ++w) {
+            u64* dst = xchg_box(peers.arena[w], slot, world, rank, slot_doubles) + 2 * (size_t)i;
+            XCHG_ST(dst, w0);
+            XCHG_ST(dst + 1, w1);
+        }
+    }
+    // 2. pull, source by source in rank order
+    double acc[XCHG_PER_LANE];
+#pragma unroll
+    for (int j = 0; j < XCHG_PER_LANE; ++j) acc[j] = 0.0;
+    const long long t0 = wall_clock64();
+    bool gave_up = false;
+    for (int w = 0; w < world && !gave_up; ++w) {
+        const u64* src = xchg_box(peers.arena[rank], slot, world, w, slot_doubles);
+        unsigned pending = 0;
+#pragma unroll
+        for (int j = 0; j < XCHG_PER_LANE; ++j)
+            if (tid + j * XCHG_THREADS < n) pending |= 1u << j;
+        while (pending) {
+            u64 a[XCHG_PER_LANE], b[XCHG_PER_LANE];
+#pragma unroll
+            for (int j = 0; j < XCHG_PER_LANE; ++j) {  // every outstanding word pair in flight together
+                if (pending & (1u << j)) {
+                    const size_t i = (size_t)(tid + j * XCHG_THREADS);
+                    a[j] = XCHG_LD(src + 2 * i);
+                    b[j] = XCHG_LD(src + 2 * i + 1);
+                }
             }
-            __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+            for (int j = 0; j < XCHG_PER_LANE; ++j) {
+                if ((pending & (1u << j)) && (a[j] >> 32) == (tag >> 32) && (b[j] >> 32) == (tag >> 32)) {
+                    acc[j] += __longlong_as_double((long long)((a[j] & 0xffffffffULL) | (b[j] << 32)));
+                    pending &= ~(1u << j);
+                }
+            }
+            if (pending) {
+                if (wall_clock64() - t0 > timeout_ticks) {
+                    timed_out = 1;
+                    gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
         }
     }
     __syncthreads();
-    __threadfence_system();
-    // 4. sum in rank order
     if (timed_out) {
         if (tid == 0) *status = 1;
         const double nan = __longlong_as_double(0x7ff8000000000000LL);
-        for (int i = tid; i < n; i += blockDim.x) data[i] = nan;
+        for (int i = tid; i < n; i += XCHG_THREADS) data[i] = nan;
     } else {
-        char* mine = peers.arena[rank];
-        for (int i = tid; i < n; i += blockDim.x) {
-            double s = 0.0;
-            for (int w = 0; w < world; ++w)
-                s += __hip_atomic_load(xchg_box(mine, slot, world, w, slot_doubles) + i, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_SYSTEM);
-            data[i] = s;
+#pragma unroll
+        for (int j = 0; j < XCHG_PER_LANE; ++j) {
+            const int i = tid + j * XCHG_THREADS;
+            if (i < n) data[i] = acc[j];
         }
     }
     if (tid == 0) *counter = seq;
 }
 
-__global__ __launch_bounds__(512) void xchg_allreduce_kernel(double* __restrict__ data, int n, XchgPeers peers, int world,
-                                                             int rank, unsigned long long* __restrict__ counter,
+__global__ __launch_bounds__(XCHG_THREADS) void xchg_allreduce_kernel(double* __restrict__ data, int n, XchgPeers peers, int world,
+                                                             int rank, u64* __restrict__ counter,
                                                              int slot_doubles, long long timeout_ticks,
                                                              int* __restrict__ status) {
     xchg_allreduce_body(data, n, peers, world, rank, counter, slot_doubles, timeout_ticks, status);
@@ -112,8 +140,8 @@ struct XchgFinalize {
     int c, clamp_var;
 };
 
-__global__ __launch_bounds__(512) void xchg_bn_finalize_kernel(double* __restrict__ sums, XchgPeers peers, int world,
-                                                               int rank, unsigned long long* __restrict__ counter,
+__global__ __launch_bounds__(XCHG_THREADS) void xchg_bn_finalize_kernel(double* __restrict__ sums, XchgPeers peers, int world,
+                                                               int rank, u64* __restrict__ counter,
                                                                int slot_doubles, long long timeout_ticks,
                                                                int* __restrict__ status, XchgFinalize f) {
     xchg_allreduce_body(sums, 2 * f.c, peers, world, rank, counter, slot_doubles, timeout_ticks, status);
@@ -141,9 +169,8 @@ __global__ __launch_bounds__(512) void xchg_bn_finalize_kernel(double* __restric
 }
 
 extern "C" size_t vspw_xchg_arena_bytes(int world, int slot_doubles) {
-    if (world < 1 || world > XCHG_MAX_WORLD || slot_doubles < 1) return 0;
-    if ((size_t)XCHG_SLOTS * world * sizeof(unsigned long long) > XCHG_FLAG_BYTES) return 0;
-    return XCHG_FLAG_BYTES + (size_t)XCHG_SLOTS * world * slot_doubles * sizeof(double);
+    if (world < 1 || world > XCHG_MAX_WORLD || slot_doubles < 1 || slot_doubles > XCHG_THREADS * XCHG_PER_LANE) return 0;
+    return (size_t)XCHG_SLOTS * world * 2 * slot_doubles * sizeof(u64);
 }
 
 extern "C" int vspw_xchg_handle_bytes(void) { return (int)sizeof(hipIpcMemHandle_t); }
@@ -215,7 +242,7 @@ extern "C" int vspw_xchg_allreduce_f64(double* data, int n, void* const* arenas,
     for (int w = 0; w < world; ++w)
         if (!peers.arena[w]) return VSPW_EINVAL;
     const long long ticks = (long long)(timeout_s * 1e8);  // wall_clock64: 100 MHz
-    hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(1), dim3(512), 0, vspw_stream(stream), data, n, peers, world, rank,
+    hipLaunchKernelGGL(xchg_allreduce_kernel, dim3(1), dim3(XCHG_THREADS), 0, vspw_stream(stream), data, n, peers, world, rank,
                        counter, slot_doubles, ticks, status);
     return vspw_launch_status();
 }
@@ -236,7 +263,7 @@ extern "C" int vspw_xchg_bn_finalize(double* sums, int c, void* const* arenas, i
     for (int w = 0; w < world; ++w)
         if (!peers.arena[w]) return VSPW_EINVAL;
     XchgFinalize f = {count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, c, clamp_var};
-    hipLaunchKernelGGL(xchg_bn_finalize_kernel, dim3(1), dim3(512), 0, vspw_stream(stream), sums, peers, world, rank,
+    hipLaunchKernelGGL(xchg_bn_finalize_kernel, dim3(1), dim3(XCHG_THREADS), 0, vspw_stream(stream), sums, peers, world, rank,
                        counter, slot_doubles, (long long)(timeout_s * 1e8), status, f);
     return vspw_launch_status();
 }

@@ -404,3 +404,104 @@ extern "C" int vspw_sgd_multi(const vspw_sgd_entry* entries, int n_entries, long
                        n_entries, momentum, lr_table);
     return vspw_launch_status();
 }
+
+// ---- plane gathers of the flow plumbing (NCHW planes: [planes][h][w]) ------------------------------------------
+// nearest resize  : F.interpolate(flow, size, mode='nearest') (models/netwarp.py:199,214; models/netwarp_ocr.py:252):
+//                   src = min(floor(dst * (float)in / out), in - 1), ATen's nearest_idx with a float32 scale
+// shift           : out[y][x] = in[y - top][x - left] or 0 outside: F.pad(mode='constant') of RAFT's InputPadder
+//                   (RAFT_core/utils/utils.py:7-25) for top, left >= 0 and its unpad crop (:25) for negative offsets
+// unnormalize     : (x * std[c] + mean[c]) * 255 - the image un-normalisation in front of the flow network
+//                   (models/netwarp.py:186-187), separately rounded products / sums like ATen's elementwise ops
+__global__ __launch_bounds__(256) void nearest_resize_fwd_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                 long long planes, int h, int w, int oh, int ow) {
+    const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;
+    const long long total = planes * oh * ow;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % ow);
+        long long r = i / ow;
+        const int y = (int)(r % oh);
+        const long long p = r / oh;
+        const int iy = min((int)floorf((float)y * sy), h - 1), ix = min((int)floorf((float)x * sx), w - 1);
+        out[i] = in[(p * h + iy) * w + ix];
+    }
+}
+
+// adjoint as a gather: an input pixel collects the gradient of every output pixel that selected it
+__global__ __launch_bounds__(256) void nearest_resize_bwd_kernel(const float* __restrict__ dout, float* __restrict__ din,
+                                                                 long long planes, int h, int w, int oh, int ow) {
+    const float sy = (float)h / (float)oh, sx = (float)w / (float)ow;
+    const long long total = planes * h * w;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ix = (int)(i % w);
+        long long r = i / w;
+        const int iy = (int)(r % h);
+        const long long p = r / h;
+        int y0 = (int)floorf((float)iy / sy) - 1, y1 = (int)floorf((float)(iy + 1) / sy) + 1;
+        int x0 = (int)floorf((float)ix / sx) - 1, x1 = (int)floorf((float)(ix + 1) / sx) + 1;
+        y0 = max(y0, 0); x0 = max(x0, 0); y1 = min(y1, oh - 1); x1 = min(x1, ow - 1);
+        float g = 0.f;
+        for (int y = y0; y <= y1; ++y) {
+            if (min((int)floorf((float)y * sy), h - 1) != iy) continue;
+            for (int x = x0; x <= x1; ++x)
+                if (min((int)floorf((float)x * sx), w - 1) == ix) g += dout[(p * oh + y) * ow + x];
+        }
+        din[i] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void plane_shift_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                          long long planes, int h, int w, int oh, int ow, int top,
+                                                          int left) {
+    const long long total = planes * oh * ow;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % ow);
+        long long r = i / ow;
+        const int y = (int)(r % oh);
+        const long long p = r / oh;
+        const int iy = y - top, ix = x - left;
+        out[i] = ((unsigned)iy < (unsigned)h && (unsigned)ix < (unsigned)w) ? in[(p * h + iy) * w + ix] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void unnormalize_kernel(const float* __restrict__ in, float* __restrict__ out, int c,
+                                                          long long hw, long long total, float3 stdv, float3 meanv,
+                                                          float post) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)((i / hw) % c);
+        const float s = ch == 0 ? stdv.x : (ch == 1 ? stdv.y : stdv.z), m = ch == 0 ? meanv.x : (ch == 1 ? meanv.y : meanv.z);
+        out[i] = __fmul_rn(__fadd_rn(__fmul_rn(in[i], s), m), post);
+    }
+}
+
+extern "C" int vspw_nearest_resize_fwd(const float* in, float* out, long long planes, int h, int w, int oh, int ow,
+                                       void* stream) {
+    if (!in || !out || planes < 1 || h < 1 || w < 1 || oh < 1 || ow < 1) return VSPW_EINVAL;
+    hipLaunchKernelGGL(nearest_resize_fwd_kernel, dim3(vspw_stream_grid(planes * oh * ow, 256)), dim3(256), 0,
+                       vspw_stream(stream), in, out, planes, h, w, oh, ow);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_nearest_resize_bwd(const float* dout, float* din, long long planes, int h, int w, int oh, int ow,
+                                       void* stream) {
+    if (!dout || !din || planes < 1 || h < 1 || w < 1 || oh < 1 || ow < 1) return VSPW_EINVAL;
+    hipLaunchKernelGGL(nearest_resize_bwd_kernel, dim3(vspw_stream_grid(planes * h * w, 256)), dim3(256), 0,
+                       vspw_stream(stream), dout, din, planes, h, w, oh, ow);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_plane_shift(const float* in, float* out, long long planes, int h, int w, int oh, int ow, int top,
+                                int left, void* stream) {
+    if (!in || !out || planes < 1 || h < 1 || w < 1 || oh < 1 || ow < 1) return VSPW_EINVAL;
+    hipLaunchKernelGGL(plane_shift_kernel, dim3(vspw_stream_grid(planes * oh * ow, 256)), dim3(256), 0,
+                       vspw_stream(stream), in, out, planes, h, w, oh, ow, top, left);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_unnormalize_rgb(const float* in, float* out, int n, long long hw, float s0, float s1, float s2,
+                                    float m0, float m1, float m2, float post, void* stream) {
+    if (!in || !out || n < 1 || hw < 1) return VSPW_EINVAL;
+    const long long total = (long long)n * 3 * hw;
+    hipLaunchKernelGGL(unnormalize_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream), in, out,
+                       3, hw, total, make_float3(s0, s1, s2), make_float3(m0, m1, m2), post);
+    return vspw_launch_status();
+}

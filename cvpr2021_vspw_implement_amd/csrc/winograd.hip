@@ -184,9 +184,14 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
 //   FRONT: the BatchNorm-backward front end of the node that produced this convolution's input (data gradient only):
 //          o = relu_src > 0 ? o : 0, partial sums of o and o * (bn_y - mean) * invstd  (see IgemmNT in conv_igemm.hip)
 //   stats (stat_part != nullptr, forward): partial sums of o and o*o for the training-mode BatchNorm that follows.
-// A workgroup owns WINO_TB tiles x CL4 channel quads (grid.y walks the channel quads) and leaves one [2][K] partial
+// A workgroup owns WINO_TB (= wino_tb()) tiles x CL4 channel quads (grid.y walks the channel quads) and leaves one [2][K] partial
 // row per blockIdx.x, summed over its tiles in a fixed order.
-#define WINO_TB 32
+// (measured, 256 -> 256 layer3 shape, T = 9 000 tiles: 32 tiles per workgroup give 282 workgroups - barely one per CU,
+// 4 waves to hide 16 plane-strided loads each behind; 8 tiles per workgroup give 1 125)
+static int wino_tb() {
+    static const int v = getenv("VSPW_WINO_TB") ? atoi(getenv("VSPW_WINO_TB")) : 8;
+    return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 8;
+}
 
 template <bool FRONT>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ m, const float* __restrict__ bias,
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                                                           const float* __restrict__ bn_invstd,
                                                           float* __restrict__ stat_part,
                                                           const float* __restrict__ addend, int act, WinoGeom g, int K,
-                                                          int cl4) {
+                                                          int cl4, int WINO_TB) {
     __shared__ f32x4 red[2][256];
     const int tid = threadIdx.x;
     const int lane_c = tid % cl4, lane_t = tid / cl4;
@@ -371,7 +376,7 @@ extern "C" long long vspw_wino_tiles(const vspw_conv_desc* d) {
 
 extern "C" size_t vspw_wino_stat_partials(const vspw_conv_desc* d) {
     WinoGeom g;
-    return wino_geom(d, g) ? (size_t)vspw_cdiv(g.T, WINO_TB) : 0;
+    return wino_geom(d, g) ? (size_t)vspw_cdiv(g.T, wino_tb()) : 0;
 }
 
 extern "C" int vspw_wino_weights(const float* w, float* u, int k, int c, int data_gradient, void* stream) {
@@ -400,13 +405,14 @@ extern "C" int vspw_wino_output(const vspw_conv_desc* d, const float* m, int cha
     if (!wino_geom(d, g) || !m || !y || cl4 == 0) return VSPW_EINVAL;
     const bool front = relu_src != nullptr;
     if (front && (!bn_y || !bn_mean || !bn_invstd || !stat_part)) return VSPW_EINVAL;
-    const dim3 grid(vspw_cdiv(g.T, WINO_TB), channels / 4 / cl4);
+    const int tb = wino_tb();
+    const dim3 grid(vspw_cdiv(g.T, tb), channels / 4 / cl4);
     if (front)
         hipLaunchKernelGGL(wino_output_kernel<true>, grid, dim3(256), 0, vspw_stream(stream), m, bias, y, relu_src, bn_y,
-                           bn_mean, bn_invstd, stat_part, nullptr, 0, g, channels, cl4);
+                           bn_mean, bn_invstd, stat_part, nullptr, 0, g, channels, cl4, tb);
     else
         hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(256), 0, vspw_stream(stream), m, bias, y, nullptr, nullptr,
-                           nullptr, nullptr, stat_part, addend, act, g, channels, cl4);
+                           nullptr, nullptr, stat_part, addend, act, g, channels, cl4, tb);
     return vspw_launch_status();
 }
 

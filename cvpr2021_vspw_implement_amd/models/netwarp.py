@@ -8,7 +8,6 @@ nn.Module with RAFT's forward(img1, img2, iters, test_mode) -> (low, up) signatu
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import nn as vnn
 from .. import ops
@@ -60,7 +59,7 @@ def _pad_to_8(x):
     h, w = x.shape[-2:]
     ph, pw = (((h // 8) + 1) * 8 - h) % 8, (((w // 8) + 1) * 8 - w) % 8
     pad = [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]
-    return F.pad(x, pad, mode="constant"), pad
+    return ops.plane_shift(x, (h + ph, w + pw), pad[2], pad[0]), pad
 
 
 class _NetWarpBase(LrGroupsMixin, nn.Module):
@@ -106,17 +105,16 @@ class _NetWarpBase(LrGroupsMixin, nn.Module):
             b, _ = _pad_to_8(prev255)
             _, flow = self.raft(a, b, iters=20, test_mode=True)
             hh, ww = flow.shape[-2:]
-            return flow[..., pad[2]:hh - pad[3], pad[0]:ww - pad[1]].contiguous()
+            return ops.plane_shift(flow, (hh - pad[2] - pad[3], ww - pad[0] - pad[1]), -pad[2], -pad[0])  # unpad
 
     def _refined_flow(self, feed_dict):
         c_img = feed_dict["img_data"]
         clip_imgs = feed_dict["clipimgs_data"]
         assert len(clip_imgs) == 1
         c_pre_img = clip_imgs[0]
-        mean = self.mean.to(c_img.device).view(1, 3, 1, 1)
-        std = self.std.to(c_img.device).view(1, 3, 1, 1)
-        c_img_f = (c_img * std + mean) * 255.0  # image un-normalisation: input plumbing for the flow net
-        c_pre_img_f = (c_pre_img * std + mean) * 255.0
+        # image un-normalisation (x * std + mean) * 255: input plumbing for the flow net
+        c_img_f = ops.unnormalize_rgb(c_img, self.std.tolist(), self.mean.tolist(), 255.0)
+        c_pre_img_f = ops.unnormalize_rgb(c_pre_img, self.std.tolist(), self.mean.tolist(), 255.0)
         flow = feed_dict["flow"] if "flow" in feed_dict else self._flow(c_img_f, c_pre_img_f)
         return c_img, c_pre_img, self.flowcnn(c_img_f, c_pre_img_f, flow)
 
@@ -124,7 +122,7 @@ class _NetWarpBase(LrGroupsMixin, nn.Module):
         """feats = [current; previous] stacked on the batch: blend the current half with the flow-warped previous."""
         B = feats.shape[0] // 2
         cur, prev = ops.split_batch(feats, B)
-        flow_s = F.interpolate(flow, cur.shape[-2:], mode="nearest")  # nearest, magnitudes NOT rescaled (quirk)
+        flow_s = ops.nearest_resize(flow, cur.shape[-2:])  # nearest, magnitudes NOT rescaled (quirk)
         return ops.chan_blend(cur, ops.flowwarp(prev, flow_s), w_cur, w_warp), prev
 
 

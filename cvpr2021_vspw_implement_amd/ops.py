@@ -248,10 +248,11 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
     return v
 
 
-def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None):
+def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None, wgrad=True):
     """x NHWC-memory [N,C,H,W]; w [K,C,KH,KW] in channels_last memory ([K][KH][KW][C]).
     pending = (y_prev, scale_shift, residual): x has not been written yet - it is relu(scale*y_prev + shift +
-    residual) of the node that produced it; this (pointwise) GEMM evaluates it while staging and fills x."""
+    residual) of the node that produced it; this (pointwise) GEMM evaluates it while staging and fills x.
+    wgrad: a weight gradient will be asked for (the autograd node's needs_input_grad of w)."""
     _require_gpu(x, "conv2d")
     x = to_nhwc(x)
     if not is_nhwc(w):
@@ -266,9 +267,12 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None)
         if want_stats:
             part = torch.empty((_C.query("vspw_wino_stat_partials", ctypes.byref(d)), 2, k), device=x.device,
                                dtype=torch.float32)
-        # the input transform is kept for this convolution's weight gradient (same V: saves its recomputation there)
-        v = _wino_conv(d, x, w, k, c, False, bias, y, part=part)
-        if _wino["keep_v"] and v is not None:
+        # the input transform is kept for this convolution's weight gradient (same V: saves its recomputation there) -
+        # only when there will be one: frozen weights / no_grad evaluation take the GEMM that transforms its A operand
+        # itself (V, four times the size of x, is then never written)
+        needs_v = _wino["keep_v"] and bool(wgrad) and _wino["wgrad"]
+        v = _wino_conv(d, x, w, k, c, False, bias, y, part=part, fuse=None if needs_v else True)
+        if needs_v and v is not None:
             y._vspw_wino_v = v  # picked up (and removed) by the autograd node that called us
         return y, part, d
     if want_stats:
@@ -581,7 +585,7 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, stride, pad, dil):
         x = to_nhwc(x)
-        y, _, d = conv2d_forward(x, w, bias, stride, pad, dil)
+        y, _, d = conv2d_forward(x, w, bias, stride, pad, dil, wgrad=ctx.needs_input_grad[1])
         ctx.d = d
         ctx.has_bias = bias is not None
         ctx.wino_v = getattr(y, "_vspw_wino_v", None)
@@ -918,7 +922,8 @@ class ConvBNActFn(torch.autograd.Function):
         dd = _conv_desc(x, w.shape[0], w.shape[2], w.shape[3], stride, pad, dil)
         small = training and dd.n * dd.oh * dd.ow <= _BN_SMALL_ROWS  # exact two-pass statistics (vspw_bn_small_finalize)
         fuse_stats = training and not small
-        y, part, d = conv2d_forward(x, w, cbias, stride, pad, dil, want_stats=fuse_stats, pending=pending)
+        y, part, d = conv2d_forward(x, w, cbias, stride, pad, dil, want_stats=fuse_stats, pending=pending,
+                                    wgrad=ctx.needs_input_grad[1])
         n, c, h, wd = y.shape
         rows = n * h * wd
         dev = x.device
@@ -1910,3 +1915,55 @@ class ScaleFn(torch.autograd.Function):
 
 def scale(x, a):
     return ScaleFn.apply(x, a)
+
+
+# --------------------------------------------------------------------------------------------------- flow plumbing
+class NearestResizeFn(torch.autograd.Function):
+    """F.interpolate(x, size, mode='nearest') on NCHW planes (the flow field of the NetWarp heads, netwarp.py:199,214)."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        _require_gpu(x, "nearest_resize")
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        oh, ow = int(size[0]), int(size[1])
+        y = torch.empty((n, c, oh, ow), device=x.device, dtype=torch.float32)
+        _C.call("vspw_nearest_resize_fwd", _p(x), _p(y), n * c, h, w, oh, ow, _stream())
+        ctx.meta = (n, c, h, w, oh, ow)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w, oh, ow = ctx.meta
+        g = g.contiguous()
+        dx = torch.empty((n, c, h, w), device=g.device, dtype=torch.float32)
+        _C.call("vspw_nearest_resize_bwd", _p(g), _p(dx), n * c, h, w, oh, ow, _stream())
+        return dx, None
+
+
+def nearest_resize(x, size):
+    return NearestResizeFn.apply(x, tuple(size))
+
+
+def plane_shift(x, out_hw, top, left):
+    """out[..., y, x] = x[..., y - top, x - left], zero outside (no autograd: image / frozen-flow plumbing): constant
+    padding for top, left >= 0, a crop for negative offsets."""
+    _require_gpu(x, "plane_shift")
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    y = torch.empty((n, c, int(out_hw[0]), int(out_hw[1])), device=x.device, dtype=torch.float32)
+    _C.call("vspw_plane_shift", _p(x), _p(y), n * c, h, w, int(out_hw[0]), int(out_hw[1]), int(top), int(left), _stream())
+    return y
+
+
+def unnormalize_rgb(x, std, mean, post=255.0):
+    """(x * std[c] + mean[c]) * post for an NCHW RGB batch (no autograd)."""
+    _require_gpu(x, "unnormalize_rgb")
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    if c != 3:
+        raise RuntimeError("unnormalize_rgb: 3 channels expected, got %d" % c)
+    y = torch.empty_like(x)
+    _C.call("vspw_unnormalize_rgb", _p(x), _p(y), n, h * w, float(std[0]), float(std[1]), float(std[2]), float(mean[0]),
+            float(mean[1]), float(mean[2]), float(post), _stream())
+    return y

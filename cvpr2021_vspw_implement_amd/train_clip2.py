@@ -306,7 +306,11 @@ def main(cfg, gpus, args):
         args._work_stream = torch.cuda.Stream(device)
         args._work_stream.wait_stream(torch.cuda.current_stream(device))
         torch.cuda.set_stream(args._work_stream)
-        segmentation_module = vdist.DataParallelOverRCCL(segmentation_module)
+        # SyncBN inverse standard deviation over several devices: the reference's multi-device path computes
+        # clamp(var, eps)^-1/2 (models/sync_batchnorm/batchnorm.py:150), its single-device path (var + eps)^-1/2;
+        # "reference" reproduces the former, "single" makes N ranks compute what ONE device would on the whole batch
+        segmentation_module = vdist.DataParallelOverRCCL(
+            segmentation_module, sync_bn_clamp_var=getattr(args, "syncbn_formula", "reference") == "reference")
 
     history = {"train": {"epoch": [], "loss": [], "acc": []}}
     for epoch in range(cfg.TRAIN.start_epoch, cfg.TRAIN.num_epoch):
@@ -386,6 +390,9 @@ def build_parser():
     # additions (no reference counterpart): checkpoint period (the reference hard-codes 20, train_clip2.py:386) and the
     # RAFT checkpoint NetWarp loads (models/netwarp.py:72 hard-codes this path)
     p.add_argument("--ckpt_every", type=int, default=20)
+    p.add_argument("--syncbn_formula", default="reference", choices=["reference", "single"],
+                   help="several ranks: 'reference' = clamp(var, eps)^-1/2 like the reference's multi-GPU SyncBN "
+                        "(batchnorm.py:150), 'single' = (var + eps)^-1/2 like one device on the full batch")
     p.add_argument("--hip_graph", action="store_true",
                    help="replay the training step as one captured hipGraph (fixed crop / batch shapes; no reference "
                         "counterpart)")

@@ -423,6 +423,20 @@ size_t vspw_nl_dot_workspace(int b, int n, int c);
 int vspw_nl_dot(const float* q, const float* k, const float* v, float* out, int b, int n, int c, float scale, void* ws,
                 size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------- flow plumbing (misc.hip) ---------- */
+/* Plane gathers on NCHW data [planes][h][w] around the flow network of the NetWarp heads:
+ *   vspw_nearest_resize_fwd / bwd  F.interpolate(flow, size, mode='nearest') and its adjoint (models/netwarp.py:199,214;
+ *                                  models/netwarp_ocr.py:252): src = min(floor(dst * (float)in / out), in - 1);
+ *   vspw_plane_shift               out[y][x] = in[y - top][x - left], 0 outside: F.pad(mode='constant') of RAFT's
+ *                                  InputPadder (RAFT_core/utils/utils.py:7-25) and, with negative offsets, its unpad crop;
+ *   vspw_unnormalize_rgb           (x * std[c] + mean[c]) * post on [n][3][hw] (models/netwarp.py:186-187). */
+int vspw_nearest_resize_fwd(const float* in, float* out, long long planes, int h, int w, int oh, int ow, void* stream);
+int vspw_nearest_resize_bwd(const float* dout, float* din, long long planes, int h, int w, int oh, int ow, void* stream);
+int vspw_plane_shift(const float* in, float* out, long long planes, int h, int w, int oh, int ow, int top, int left,
+                     void* stream);
+int vspw_unnormalize_rgb(const float* in, float* out, int n, long long hw, float s0, float s1, float s2, float m0, float m1,
+                         float m2, float post, void* stream);
+
 /* ---------------------------------------------------------------- peer statistics exchange (exchange.hip) --- */
 /* The cross-replica sum of SynchronizedBatchNorm (models/sync_batchnorm/batchnorm.py:110-131, comm.py:59-137: the
  * master replica collects [sum, ssum, count] of every device and hands the totals back) for one process per GPU: every

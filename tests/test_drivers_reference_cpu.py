@@ -89,7 +89,7 @@ def test_argparse_surface_equals_reference(fx, driver):
     if driver == "train_clip2.py":
         from cvpr2021_vspw_implement_amd.train_clip2 import build_parser
 
-        extra_ok = {"ckpt_every", "raft_weights", "hip_graph"}
+        extra_ok = {"ckpt_every", "raft_weights", "hip_graph", "syncbn_formula"}
     else:
         from cvpr2021_vspw_implement_amd.test_clip2 import build_parser
 

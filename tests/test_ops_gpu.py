@@ -664,3 +664,37 @@ def test_avg_pool2x2_matches_aten_semantics(dev, shape):
     dx = torch.zeros_like(x)
     dx[:, :, :h // 2 * 2, :w // 2 * 2] = (dy * 0.25).repeat_interleave(2, 2).repeat_interleave(2, 3)
     assert torch.equal(xd.grad.cpu().contiguous(), dx)
+
+
+@pytest.mark.parametrize("hw,out", [((479, 479), (60, 60)), ((480, 853), (60, 107)), ((7, 9), (15, 20)), ((60, 60), (60, 60))])
+def test_flow_plumbing_gathers_match_aten(dev, hw, out):
+    """The three data-movement ops around the flow network, bit-exact against the ATen calls the reference makes
+    (evaluated here by torch on the CPU): F.interpolate(flow, size, mode='nearest') forward AND adjoint
+    (models/netwarp.py:199,214), F.pad(mode='constant') / the unpad crop of RAFT's InputPadder (utils/utils.py:7-25),
+    (img * std + mean) * 255 (models/netwarp.py:186-187)."""
+    import torch.nn.functional as F
+
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    h, w = hw
+    flow = torch.randn(2, 2, h, w, generator=g)
+    dy = torch.randn(2, 2, *out, generator=g)
+    ref = flow.clone().requires_grad_(True)
+    want = F.interpolate(ref, out, mode="nearest")
+    want.backward(dy)
+    x = flow.to(dev).requires_grad_(True)
+    got = ops.nearest_resize(x, out)
+    got.backward(dy.to(dev))
+    assert torch.equal(got.detach().cpu(), want.detach())
+    assert torch.allclose(x.grad.cpu(), ref.grad, rtol=0, atol=1e-6)  # (sums of <= 4 terms when up-sampling)
+    img = torch.randn(2, 3, h, w, generator=g)
+    ph, pw = (((h // 8) + 1) * 8 - h) % 8, (((w // 8) + 1) * 8 - w) % 8
+    pad = [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]
+    padded = ops.plane_shift(img.to(dev), (h + ph, w + pw), pad[2], pad[0])
+    assert torch.equal(padded.cpu(), F.pad(img, pad, mode="constant"))
+    back = ops.plane_shift(padded, (h, w), -pad[2], -pad[0])
+    assert torch.equal(back.cpu(), img)
+    mean, std = torch.FloatTensor([0.485, 0.456, 0.406]), torch.FloatTensor([0.229, 0.224, 0.225])
+    un = ops.unnormalize_rgb(img.to(dev), std.tolist(), mean.tolist(), 255.0)
+    assert torch.equal(un.cpu(), (img * std.view(1, 3, 1, 1) + mean.view(1, 3, 1, 1)) * 255.0)

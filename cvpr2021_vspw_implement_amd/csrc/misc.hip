@@ -466,10 +466,13 @@ __global__ __launch_bounds__(256) void plane_shift_kernel(const float* __restric
 __global__ __launch_bounds__(256) void unnormalize_kernel(const float* __restrict__ in, float* __restrict__ out, int c,
                                                           long long hw, long long total, float3 stdv, float3 meanv,
                                                           float post) {
+#pragma clang fp contract(off)  // x*std, +mean, *post each rounded on its own (hipcc contracts a*b+c into an FMA by default)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int ch = (int)((i / hw) % c);
         const float s = ch == 0 ? stdv.x : (ch == 1 ? stdv.y : stdv.z), m = ch == 0 ? meanv.x : (ch == 1 ? meanv.y : meanv.z);
-        out[i] = __fmul_rn(__fadd_rn(__fmul_rn(in[i], s), m), post);
+        const float t = in[i] * s;
+        const float u = t + m;
+        out[i] = u * post;
     }
 }
 

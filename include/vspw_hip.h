@@ -29,7 +29,7 @@ extern "C" {
 #define VSPW_EINVAL (-1)  /* bad argument / geometry / workspace too small */
 #define VSPW_ELAUNCH (-2) /* hipLaunchKernel reported an error */
 
-#define VSPW_ABI_VERSION 3
+#define VSPW_ABI_VERSION 4
 int vspw_abi_version(void);
 /* The hipError_t behind the most recent VSPW_ELAUNCH (0 if none) - for error messages. */
 int vspw_last_hip_error(void);

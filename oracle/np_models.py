@@ -244,12 +244,45 @@ def _flat_w(sd, keys):
             sd[k] = sd[k].reshape(sd[k].shape[:2] + (1, 1))
 
 
-def nonlocal2d(P, feats, pre, training, seg_size=None):
-    """reference models/non_local_models.py:124-151 (Non_local2d.forward)."""
+def nonlocal2d(P, feats, pre, training, seg_size=None, downsample=False):
+    """reference models/non_local_models.py:124-151 (Non_local2d.forward); downsample (:135-138): the block runs on
+    the 2x2-average-pooled embedding and its output is bilinearly resized back."""
     emb = _conv(P, feats[-1], pre + "emb")
     b, c, h, w = emb.shape
-    z = nl_block(P, O.reshape(emb, (b, c, h * w, 1)), pre + "nonlocalblock.", training)
-    pred = _conv(P, O.cat([emb, O.reshape(z, (b, c, h, w))], 1), pre + "last_layer")
+    src = O.avg_pool2x2(emb) if downsample else emb
+    hs, ws = src.shape[2:]
+    z = O.reshape(nl_block(P, O.reshape(src, (b, c, hs * ws, 1)), pre + "nonlocalblock.", training), (b, c, hs, ws))
+    if downsample:
+        z = O.interpolate_bilinear(z, (h, w))
+    pred = _conv(P, O.cat([emb, z], 1), pre + "last_layer")
     if seg_size is not None:
         return O.softmax(O.interpolate_bilinear(pred, seg_size), 1)
     return O.log_softmax(pred, 1)
+
+
+def nonlocal3d(P, arch, frames, labels, training, seg_size=None, downsample=False):
+    """reference models/non_local_models.py:19-72 (Non_local3d.forward): one non-local block over the T*h*w positions of
+    a clip ([B,C,T,h,w], Conv3d 1x1x1 = per-position linear maps); per-frame losses / accuracies are averaged."""
+    T = len(frames)
+    B = frames[0].shape[0]
+    emb = _conv(P, resnet_dilated(P, Var(np.concatenate(frames, 0)), arch, "encoder.", training)[-1], "emb")
+    n, c, h, w = emb.shape
+    src = O.avg_pool2x2(emb) if downsample else emb
+    hs, ws = src.shape[2:]
+    # [T*B,C,hs,ws] -> per clip [B, C, T*hs*ws, 1]
+    x = O.transpose(O.reshape(src, (T, B, c, hs * ws)), (1, 2, 0, 3))
+    z = nl_block(P, O.reshape(x, (B, c, T * hs * ws, 1)), "nonlocalblock.", training)
+    z = O.reshape(O.transpose(O.reshape(z, (B, c, T, hs * ws)), (2, 0, 1, 3)), (n, c, hs, ws))
+    if downsample:
+        z = O.interpolate_bilinear(z, (h, w))
+    pred = _conv(P, O.cat([emb, z], 1), "last_layer")
+    preds = O.split_batch(pred, B)
+    if seg_size is not None:
+        return [O.softmax(O.interpolate_bilinear(p, seg_size), 1) for p in preds]
+    loss, acc = None, 0.0
+    for p, lab in zip(preds, labels):
+        pu = O.interpolate_bilinear(O.log_softmax(p, 1), lab.shape[2:])
+        l_ = O.nll_loss(pu, lab)
+        loss = l_ if loss is None else O.add(loss, l_)
+        acc += O.pixel_acc(pu.v, lab)
+    return O.scale(loss, 1.0 / T), acc / T

@@ -2387,8 +2387,17 @@ extern "C" size_t vspw_conv2d_bwd_aff_supported(const vspw_conv_desc* d) {
 // M[xi] = (B^T d B)[xi] . U[xi]^T for the 16 Winograd positions in one launch, the input transform evaluated while the A
 // operand is staged (IgemmNT::wino_d): src = x (forward) or dY (data gradient), NHWC with `channels` channels;
 // u [16][rows][channels]; m [16][T][rows].
+extern "C" int vspw_wino_gemm_fused_ex(const vspw_conv_desc* d, const float* src, long long ldx, int channels,
+                                       const float* u, int rows, float* m, void* stream);
 extern "C" int vspw_wino_gemm_fused(const vspw_conv_desc* d, const float* src, int channels, const float* u, int rows,
                                     float* m, void* stream) {
+    return vspw_wino_gemm_fused_ex(d, src, channels, channels, u, rows, m, stream);
+}
+
+// ... with the source read at pixel stride ldx >= channels (the first `channels` channels of a wider NHWC buffer).
+extern "C" int vspw_wino_gemm_fused_ex(const vspw_conv_desc* d, const float* src, long long ldx, int channels,
+                                       const float* u, int rows, float* m, void* stream) {
+    if (ldx < channels || (ldx & 3) || ldx > 0x7fffffff) return VSPW_EINVAL;
     if (!d || !src || !u || !m || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->dil < 1 || d->pad != d->dil ||
         d->pad_w != d->dil || d->oh != d->h || d->ow != d->w || channels % BK != 0 || rows % 4 != 0)
         return VSPW_EINVAL;
@@ -2405,6 +2414,7 @@ extern "C" int vspw_wino_gemm_fused(const vspw_conv_desc* d, const float* src, i
     p.batch = 16;
     p.bs_src = 0; p.bs_wt = (long long)rows * channels; p.bs_dst = T * rows;
     p.wino_d = dl; p.wino_th = th; p.wino_tw = tw;
+    p.lds = (int)ldx;
     bool v2;
     int cfg = nt_decide(p, v2);
     if (!v2) return VSPW_EINVAL;

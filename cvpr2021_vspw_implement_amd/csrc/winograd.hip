@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                                                           const float* __restrict__ bn_invstd,
                                                           float* __restrict__ stat_part,
                                                           const float* __restrict__ addend, int act, WinoGeom g, int K,
-                                                          int cl4, int WINO_TB) {
+                                                          int cl4, int WINO_TB, int ldy) {
     __shared__ f32x4 red[2][256];
     const int tid = threadIdx.x;
     const int lane_c = tid % cl4, lane_t = tid / cl4;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                 const int ox = (2 * tx + b) * g.d + sx;
                 if (oy >= g.h || ox >= g.w) continue;
                 f32x4 o = (b == 0 ? (r[a][0] + r[a][1] + r[a][2]) : (r[a][1] - r[a][2] - r[a][3])) + bv;
-                const size_t e = (((size_t)img * g.h + oy) * g.w + ox) * K + k;
+                const size_t e = (((size_t)img * g.h + oy) * g.w + ox) * ldy + k;  // (ldy = K except vspw_wino_output_ex)
                 if (FRONT) {
                     const f32x4 z = *reinterpret_cast<const f32x4*>(relu_src + e);
                     const f32x4 yv = *reinterpret_cast<const f32x4*>(bn_y + e);
@@ -409,10 +409,26 @@ extern "C" int vspw_wino_output(const vspw_conv_desc* d, const float* m, int cha
     const dim3 grid(vspw_cdiv(g.T, tb), channels / 4 / cl4);
     if (front)
         hipLaunchKernelGGL(wino_output_kernel<true>, grid, dim3(256), 0, vspw_stream(stream), m, bias, y, relu_src, bn_y,
-                           bn_mean, bn_invstd, stat_part, nullptr, 0, g, channels, cl4, tb);
+                           bn_mean, bn_invstd, stat_part, nullptr, 0, g, channels, cl4, tb, channels);
     else
         hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(256), 0, vspw_stream(stream), m, bias, y, nullptr, nullptr,
-                           nullptr, nullptr, stat_part, addend, act, g, channels, cl4, tb);
+                           nullptr, nullptr, stat_part, addend, act, g, channels, cl4, tb, channels);
+    return vspw_launch_status();
+}
+
+// y = act(A^T M A + bias) written with pixel stride ldy >= channels (a channel slot of a wider NHWC buffer): the frozen
+// flow network's 3x3 convolutions (RAFT_core/update.py:16-17,82-87), whose outputs land inside concatenation buffers.
+extern "C" int vspw_wino_output_ex(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
+                                   long long ldy, int act, void* stream) {
+    WinoGeom g;
+    const int cl4 = wino_cl4(channels);
+    if ((act != 0 && act != 1) || !wino_geom(d, g) || !m || !y || cl4 == 0 || ldy < channels || (ldy & 3) ||
+        ldy > 0x7fffffff)
+        return VSPW_EINVAL;
+    const int tb = wino_tb();
+    const dim3 grid(vspw_cdiv(g.T, tb), channels / 4 / cl4);
+    hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(256), 0, vspw_stream(stream), m, bias, y, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, act, g, channels, cl4, tb, (int)ldy);
     return vspw_launch_status();
 }
 

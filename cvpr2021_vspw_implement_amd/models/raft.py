@@ -177,6 +177,22 @@ class RAFT(nn.Module):
         w2, b2 = _pack(c2), c2.bias.detach()
         P["cnet.conv2.net"] = (w2[: self.hidden_dim].contiguous(), b2[: self.hidden_dim].contiguous())
         P["cnet.conv2.inp"] = (w2[self.hidden_dim:].contiguous(), b2[self.hidden_dim:].contiguous())
+        # Winograd F(2x2,3x3) weights (csrc/winograd.hip) of the update block's wide stride-1 3x3 convolutions: 38 % of
+        # an iteration's FLOPs at 4/9 of the multiplications.  `encoder.conv` has 126 outputs: two zero rows pad it to 128
+        # (the two surplus channels land in HX's flow slot, which is rewritten right after, update.py:95-96)
+        import os
+
+        if os.environ.get("VSPW_RAFT_WINOGRAD", "1") == "1":
+            for name, pad_k in (("update_block.encoder.convc2", 0), ("update_block.encoder.conv", 2),
+                                ("update_block.flow_head.conv1", 0), ("update_block.mask.0", 0)):
+                w, b = P[name]
+                if pad_k:
+                    w = torch.cat([w, torch.zeros((pad_k,) + tuple(w.shape[1:]), device=w.device)], 0).contiguous()
+                    b = torch.cat([b, torch.zeros(pad_k, device=b.device)], 0).contiguous()
+                k, c = w.shape[0], w.shape[3]
+                u = torch.empty((16, k, c), device=w.device, dtype=torch.float32)
+                _C.call("vspw_wino_weights", _p(w), _p(u), k, c, 0, _stream())
+                P["wino:" + name] = (u, b, k, c)
         self._packed = (key, P)
         return P
 
@@ -302,7 +318,25 @@ class RAFT(nn.Module):
         delta = torch.empty((rows, 2), **f32)
         ub = "update_block."
 
+        wino_m = {}
+
         def conv(x, c, ldx, key, kh, kw, pad, act, y, ldy):
+            wk = P.get("wino:" + key)
+            if wk is not None and act in (ACT_NONE, ACT_RELU):
+                # M = (B^T d B) U^T for the 16 transform positions (input transform inside the GEMM's operand staging),
+                # then y = act(A^T M A + bias) into the destination channel slot
+                u, b, k, cc = wk
+                d = ConvDesc(N, h8, w8, cc, h8, w8, k, 3, 3, 1, 1, 1, 1)
+                T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
+                m = wino_m.get(k)
+                if m is None:
+                    m = wino_m[k] = torch.empty((16, T, k), **f32)
+                GEMM_FLOPS["total"] += 2.0 * rows * k * 9 * cc       # direct-convolution FLOPs this replaces
+                GEMM_FLOPS["executed"] = GEMM_FLOPS.get("executed", 0.0) + 2.0 * 16 * T * k * cc
+                _C.call("vspw_wino_gemm_fused_ex", ctypes.byref(d), x, ldx, cc, _p(u), k, _p(m), _stream())
+                _C.call("vspw_wino_output_ex", ctypes.byref(d), _p(m), k, _p(b), y, ldy, 1 if act == ACT_RELU else 0,
+                        _stream())
+                return
             wt, b = P[key]
             _conv(x, N, h8, w8, c, ldx, wt, b, kh, kw, 1, pad, act, y, ldy)
 

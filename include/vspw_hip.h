@@ -151,6 +151,13 @@ int vspw_wino_input(const vspw_conv_desc* d, const float* x, int channels, float
  * (V is never written).  src = x or dY (NHWC, `channels`), u [16][rows][channels], m [16][T][rows]. */
 int vspw_wino_gemm_fused(const vspw_conv_desc* d, const float* src, int channels, const float* u, int rows, float* m,
                          void* stream);
+/* The same two calls for tensors that are channel slots of wider NHWC buffers (pixel strides ldx / ldy, multiples of 4):
+ * the 3x3 convolutions of the frozen flow network (RAFT_core/update.py:16-17,82-87), whose operands live inside the
+ * update block's concatenation buffers; y = act(A^T M A + bias), act 0 / 1 (ReLU). */
+int vspw_wino_gemm_fused_ex(const vspw_conv_desc* d, const float* src, long long ldx, int channels, const float* u,
+                            int rows, float* m, void* stream);
+int vspw_wino_output_ex(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
+                        long long ldy, int act, void* stream);
 int vspw_wino_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
                      const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
                      float* stat_part, const float* addend, int act, void* stream);

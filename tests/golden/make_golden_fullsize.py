@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Full-size golden vectors: the REFERENCE itself (imported read-only from /root/reference, float32 AND float64) on the
-BASELINE.json configurations at their own sizes - training steps at R101 / T=5 / B=2 / 479x479 (cfg 2, 3, 4, 5a) and
+BASELINE.json configurations at their own sizes - training steps at R101 / B=2 / 479x479 (cfg 2, 3, 4 with T=5, 5a, 5b
+Non_local3d with T=5, 5c NetWarp with a synthetic flow field) and
 inference at 480x853 (cfg 1-4) - so that the GPU tests compare stored arrays instead of evaluating an oracle live.
 Build container only (the GPU box has no /root/reference); writes arrays only (tests/golden/full_*.npz): inputs and
 weights are regenerated from seeds (oracle/det_init.py).
@@ -41,6 +42,15 @@ def rss_gb():
     return resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2 ** 20
 
 
+class FakeRaft(torch.nn.Module):
+    """stands in for RAFT: a fixed synthetic flow field with the statistics SURVEY 8(c) quotes for real RAFT output"""
+
+    def forward(self, a, b, iters=20, test_mode=True):
+        n, _, h, w = a.shape
+        f = torch.from_numpy(det_input("train479:netwarp:flow", (n, 2, h, w), scale=1.9)).to(a.dtype) - 0.7
+        return None, f.clamp(-10, 10)
+
+
 def build(M, kind, T):
     crit = torch.nn.NLLLoss(ignore_index=255)
     if kind == "r18_ppm":
@@ -54,6 +64,23 @@ def build(M, kind, T):
     if kind == "r101_nonlocal2d":
         dec = M.ModelBuilder.build_decoder(arch="nonlocal2d", fc_dim=2048, num_class=K)
         return M.SegmentationModule(enc, dec, crit, None), (lambda m: m.decoder.last_layer)
+    if kind == "nonlocal3d":
+        return M.Non_local3d(G.args_ns(), enc, crit), (lambda m: m.last_layer)
+    if kind == "netwarp":
+        # the flow network replaced by a fixed synthetic field (make_golden.case_netwarp; the RAFT checkpoint is not in
+        # the tree and RAFT itself is pinned by raft_basic.npz)
+        import models.netwarp as ref_nw
+
+        orig_raft, orig_load = ref_nw.RAFT, torch.load
+        ref_nw.RAFT = lambda: torch.nn.Identity()
+        torch.load = lambda *a, **k: {}
+        try:
+            dec = M.ModelBuilder.build_decoder(arch="ppm_deepsup_clip", fc_dim=2048, num_class=K)
+            mod = M.NetWarp(enc, dec, crit, G.args_ns(clip_num=2), deep_sup_scale=0.4)
+        finally:
+            ref_nw.RAFT, torch.load = orig_raft, orig_load
+        mod.raft = FakeRaft()
+        return mod, (lambda m: m.conv_last_)
     if kind == "clip_psp":
         return M.Clip_PSP(enc, crit, G.args_ns(clip_num=T), deep_sup_scale=0.4), (lambda m: m.ppm_conv.conv_last_)
     if kind == "clip_ocr":
@@ -62,7 +89,10 @@ def build(M, kind, T):
 
 
 def load_weights(mod, variant):
-    G.load_det(mod)
+    from oracle.det_init import det_tensor
+
+    sd = {k: v for k, v in mod.state_dict().items() if not k.startswith("raft.")}
+    mod.load_state_dict({k: torch.from_numpy(det_tensor(k, v.shape)).to(v.dtype) for k, v in sd.items()}, strict=False)
     if variant == "damped":
         sd = mod.state_dict()
         changed = damp_residual_gammas(sd)  # tensors are the module's own storage? state_dict() returns references
@@ -71,7 +101,12 @@ def load_weights(mod, variant):
     G.zero_dropout(mod)
 
 
-def feed_of(frames, labels, clip, cast=lambda t: t):
+def feed_of(frames, labels, clip, cast=lambda t: t, kind=None):
+    if kind == "nonlocal3d":  # all T frames in the lists (models/non_local_models.py:19-22)
+        return {"clipimgs_data": [cast(f) for f in frames], "cliplabels_data": [cast(l) for l in labels]}
+    if kind == "netwarp":     # current frame + ONE previous frame, no clip labels (models/netwarp.py:150-160)
+        return {"img_data": cast(frames[-1]), "seg_label": cast(labels[-1]), "clipimgs_data": [cast(frames[0])],
+                "cliplabels_data": []}
     d = {"img_data": cast(frames[-1]), "seg_label": cast(labels[-1])}
     if clip:
         d.update(clipimgs_data=[cast(f) for f in frames[:-1]], cliplabels_data=[cast(l) for l in labels[:-1]])
@@ -146,7 +181,7 @@ def case_train(M, kind, variant, tag, B=2):
     """One training step (forward, loss, backward) at 479x479, Dropout2d off, float32 then float64."""
     t0 = time.time()
     clip = kind in ("clip_psp", "clip_ocr")
-    T = 5 if clip else 1
+    T = {"clip_psp": 5, "clip_ocr": 5, "nonlocal3d": 5, "netwarp": 2}.get(kind, 1)
     mod, tap = build(M, kind, T)
     load_weights(mod, variant)
     sd = {k: v.clone() for k, v in mod.state_dict().items()}
@@ -161,7 +196,7 @@ def case_train(M, kind, variant, tag, B=2):
             as64(mod, sd)
         mod.train()
         mod.zero_grad()
-        loss, acc = mod(feed_of(frames, labels, clip, cast))
+        loss, acc = mod(feed_of(frames, labels, clip, cast, kind))
         loss.backward()
         res["loss" + suffix] = np.float64(loss.item())
         res["acc" + suffix] = np.float64(acc.item())
@@ -169,6 +204,8 @@ def case_train(M, kind, variant, tag, B=2):
         res.update(grads_pack(mod, suffix))
         if suffix == "32":
             for bn in ("encoder.bn1", "encoder.layer3.22.bn3", "encoder.layer4.2.bn3"):
+                if bn not in dict(mod.named_modules()):
+                    continue
                 m = dict(mod.named_modules())[bn]
                 res["running_mean:" + bn] = m.running_mean.numpy().copy()
                 res["running_var:" + bn] = m.running_var.numpy().copy()
@@ -186,7 +223,9 @@ def case_train(M, kind, variant, tag, B=2):
 
 
 EVAL = [("r18_ppm", "cfg1"), ("r101_ppm", "cfg2"), ("clip_psp", "cfg3"), ("clip_ocr", "cfg4")]
-TRAIN = [("r101_ppm", "cfg2"), ("clip_psp", "cfg3"), ("clip_ocr", "cfg4"), ("r101_nonlocal2d", "cfg5a")]
+TRAIN = [("r101_ppm", "cfg2"), ("clip_psp", "cfg3"), ("clip_ocr", "cfg4"), ("r101_nonlocal2d", "cfg5a"),
+         ("nonlocal3d", "cfg5b"),   # Non_local3d over T=5 frames (18 000 positions; T=7 does not fit this container in fp64)
+         ("netwarp", "cfg5c")]      # NetWarp with a synthetic flow field
 
 
 def main():

@@ -1,6 +1,7 @@
 """Every BASELINE.json configuration at ITS OWN size against vectors produced by the REFERENCE itself
 (tests/golden/make_golden_fullsize.py: /root/reference imported in the build container, float32 and float64):
-inference at 480x853 for cfg 1-4, one training step at R101 / T=5 / B=2 / 479x479 for cfg 2, 3, 4, 5a.  No oracle is
+inference at 480x853 for cfg 1-4, one training step at R101 / B=2 / 479x479 for cfg 2, 3, 4 (T=5), 5a, 5b (Non_local3d,
+T=5: 18 000 positions) and 5c (NetWarp, synthetic flow).  No oracle is
 evaluated here: stored arrays only, so the whole file takes seconds per case.
 
 Two weight variants per case (see make_golden_fullsize.py / det_init.damp_residual_gammas):
@@ -34,14 +35,27 @@ def _module(kind, T):
     if kind == "r101_nonlocal2d":
         return (build("seg", "resnet101dilated", "nonlocal2d", 2048, deep_sup_scale=None),
                 (lambda m: m.decoder.last_layer))
+    if kind == "nonlocal3d":
+        return build("nonlocal3d", "resnet101dilated"), (lambda m: m.last_layer)
+    if kind == "netwarp":
+        return build("netwarp", "resnet101dilated", flow_net=_FakeRaft()), (lambda m: m.conv_last_)
     if kind == "clip_psp":
         return build(kind, "resnet101dilated", args={"clip_num": T}), (lambda m: m.ppm_conv)
     return build(kind, "resnet101dilated", args={"clip_num": T}), (lambda m: m.head)
 
 
+class _FakeRaft(torch.nn.Module):
+    """the fixed synthetic flow field make_golden_fullsize.FakeRaft hands the reference (RAFT itself: raft_basic.npz)"""
+
+    def forward(self, a, b, iters=20, test_mode=True):
+        n, _, h, w = a.shape
+        f = torch.from_numpy(det_input("train479:netwarp:flow", (n, 2, h, w), scale=1.9)) - 0.7
+        return None, f.clamp(-10, 10).to(a.device)
+
+
 def _load(mod, variant, fx=None):
     """deterministic name-keyed weights (+ the reference-calibrated running statistics of an eval fixture)"""
-    load_det(mod, fx=fx)
+    load_det(mod, fx=fx, skip_prefix=("raft.",) if hasattr(mod, "raft") else ())
     if variant == "damped":
         sd = {k: v.clone() for k, v in mod.state_dict().items()}
         assert damp_residual_gammas(sd)
@@ -49,7 +63,11 @@ def _load(mod, variant, fx=None):
     zero_dropout(mod)
 
 
-def _feed(frames, labels, clip):
+def _feed(frames, labels, clip, kind=None):
+    if kind == "nonlocal3d":
+        return {"clipimgs_data": list(frames), "cliplabels_data": list(labels)}
+    if kind == "netwarp":
+        return {"img_data": frames[-1], "seg_label": labels[-1], "clipimgs_data": [frames[0]], "cliplabels_data": []}
     d = {"img_data": frames[-1], "seg_label": labels[-1]}
     if clip:
         d.update(clipimgs_data=list(frames[:-1]), cliplabels_data=list(labels[:-1]))
@@ -57,7 +75,8 @@ def _feed(frames, labels, clip):
 
 
 EVAL = [("r18_ppm", "cfg1"), ("r101_ppm", "cfg2"), ("clip_psp", "cfg3"), ("clip_ocr", "cfg4")]
-TRAIN = [("r101_ppm", "cfg2"), ("clip_psp", "cfg3"), ("clip_ocr", "cfg4"), ("r101_nonlocal2d", "cfg5a")]
+TRAIN = [("r101_ppm", "cfg2"), ("clip_psp", "cfg3"), ("clip_ocr", "cfg4"), ("r101_nonlocal2d", "cfg5a"),
+         ("nonlocal3d", "cfg5b"), ("netwarp", "cfg5c")]
 
 
 @pytest.mark.parametrize("variant", ["damped", "raw"])
@@ -133,7 +152,7 @@ def test_479_training_step_against_reference_vectors(dev, kind, cfg, variant):
     differs from the next by up to 1.5x; factor 3 on the maximum), with an absolute floor of 1e-3."""
     fx = golden("full_train_%s_%s_%s" % (cfg, kind, variant))
     clip = kind in ("clip_psp", "clip_ocr")
-    T = 5 if clip else 1
+    T = {"clip_psp": 5, "clip_ocr": 5, "nonlocal3d": 5, "netwarp": 2}.get(kind, 1)
     B = 2
     mod, tap = _module(kind, T)
     _load(mod, variant)
@@ -143,7 +162,7 @@ def test_479_training_step_against_reference_vectors(dev, kind, cfg, variant):
     labels = [_t(det_labels("%s:%d" % (name, t), (B, 1, S, S), K), dev) for t in range(T)]
     store = {}
     hk = tap(mod).register_forward_hook(lambda m, i, o: store.__setitem__("l", o.detach().float().cpu().numpy()))
-    loss, acc = mod(_feed(frames, labels, clip))
+    loss, acc = mod(_feed(frames, labels, clip, kind))
     hk.remove()
     loss.backward()
     torch.cuda.synchronize()

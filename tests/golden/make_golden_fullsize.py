@@ -200,7 +200,7 @@ def case_train(M, kind, variant, tag, B=2):
         loss.backward()
         res["loss" + suffix] = np.float64(loss.item())
         res["acc" + suffix] = np.float64(acc.item())
-        res["logits%s_sub" % suffix] = store["l"].numpy()[:, :, ::2, ::2].astype(np.float32)
+        res["logits%s_sub" % suffix] = store["l"].numpy()[:4, :, ::2, ::2].astype(np.float32)  # (first 4 images)
         res.update(grads_pack(mod, suffix))
         if suffix == "32":
             for bn in ("encoder.bn1", "encoder.layer3.22.bn3", "encoder.layer4.2.bn3"):

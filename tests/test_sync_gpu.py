@@ -182,7 +182,7 @@ def _protocol_worker(rank, world, port, q):
             want += vals[r]
         bad += int(not torch.equal(t, want))
     xc.check()
-    wd.phase("dead peer: rank 1 stays away, rank 0 must give up after 1 s with NaN + status")
+    wd.phase("dead peers: only rank 0 launches, it must give up after 1 s with NaN + status")
     gave_up = None
     vdist.dist.barrier()
     if rank == 0:
@@ -205,20 +205,21 @@ def _protocol_worker(rank, world, port, q):
     wd.stop()
 
 
-def test_peer_exchange_protocol_two_processes(dev):
-    """csrc/exchange.hip between two PROCESSES that map each other's arena (hipIpc) on the one device of the box: 1 500
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_exchange_protocol_between_processes(dev, world):
+    """csrc/exchange.hip between 2 and 4 PROCESSES that map each other's arenas (hipIpc) on the one device of the box: 1 500
     exchanges of ragged lengths with host stalls, stream switches and device syncs thrown in give the exact fp64 totals
     on both ranks; a peer that never arrives costs the waiting rank its timeout - not the GPU."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_protocol_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_protocol_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=150) for _ in range(2))
+    res = dict(q.get(timeout=150) for _ in range(world))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert res[0]["bad"] == 0 and res[1]["bad"] == 0, res
+    assert all(res[r]["bad"] == 0 for r in range(world)), res
     assert res[0]["gave_up"] is True
-    assert res[0]["exchanges"] == 1501 and res[1]["exchanges"] == 1500
+    assert res[0]["exchanges"] == 1501 and all(res[r]["exchanges"] == 1500 for r in range(1, world))

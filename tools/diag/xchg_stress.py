@@ -23,21 +23,19 @@ def worker(rank, world, port, q, iters):
     for k in range(iters):
         n = int(rs.choice([1, 2, 3, 128, 512, 1024, 4096, 8192]))
         # value pattern: rank r contributes (k + 1) * (r + 1) + i * 1e-3: totals identify the exchange index
-        i = torch.arange(n, dtype=torch.float64, device=dev) * 1e-3
+        i = torch.arange(n, dtype=torch.float64, device=dev) * 0.5  # (exactly representable: totals are exact)
         mine = (k + 1.0) * (rank + 1) + i
-        other = (k + 1.0) * (2 - rank) + i
         t = mine.clone()
         if own.rand() < 0.02:
             time.sleep(0.003)
         if own.rand() < 0.05:
             torch.cuda.synchronize()
         xc.all_reduce(t)
-        want = mine + other
+        want = (k + 1.0) * (world * (world + 1) / 2.0) + world * i   # exact in fp64
         if not torch.equal(t, want):
-            d = (t - mine)          # what this rank saw as the peer's contribution
             bad = (t != want).nonzero().flatten()
-            seen_k = ((d[bad] - i[bad]) / (2 - rank)).cpu().numpy() - 1.0
-            log.append((k, n, int(bad.numel()), int(bad.min()), int(bad.max()), np.unique(np.round(seen_k, 3))[:6].tolist()))
+            seen = ((t[bad] - want[bad])).cpu().numpy()
+            log.append((k, n, int(bad.numel()), int(bad.min()), int(bad.max()), np.unique(np.round(seen, 3))[:6].tolist()))
         hist[k] = n
     xc.check()
     q.put((rank, log))
@@ -48,13 +46,15 @@ if __name__ == "__main__":
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+    world = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=worker, args=(r, 2, port, q, iters)) for r in range(2)]
+    ps = [ctx.Process(target=worker, args=(r, world, port, q, iters)) for r in range(world)]
     [p.start() for p in ps]
-    res = dict(q.get(timeout=200) for _ in range(2))
+    res = dict(q.get(timeout=300) for _ in range(world))
     [p.join(30) for p in ps]
-    for r in (0, 1):
+    print("world", world, "iters", iters)
+    for r in range(world):
         print("rank", r, "bad exchanges:", len(res[r]))
         for e in res[r][:12]:
-            print("   k=%d n=%d bad=%d [%d..%d] peer contribution looks like exchange index %s" % e)
+            print("   k=%d n=%d bad=%d [%d..%d] total - expected: %s" % e)

@@ -705,12 +705,11 @@ def _finalize_name():
 # ("relu", the BatchNorm weight of the node, z) - z > 0 is the mask, read AFTER the forward pass has completed (a
 # deferred z is written by its consumer) - or ("maxpool", None, tap indices uint8 [n, oh, ow, c], ky*3+kx).  The test
 # injects them into the float64 oracle so that both differentiate the same branch of the network.
-_decisions = None
+_decisions = {"store": None}  # (a holder: the max-pool node of ops.pool reads it too)
 
 
 def record_decisions(store):
-    global _decisions
-    _decisions = store
+    _decisions["store"] = store
 
 
 class BatchNormActFn(torch.autograd.Function):
@@ -803,8 +802,8 @@ def batch_norm_act(x, gamma, beta, running_mean, running_var, residual=None, mas
                    eps=1e-5, relu=False, stat_part=None):
     z = BatchNormActFn.apply(x, gamma, beta, running_mean, running_var, residual, mask, training, momentum, eps,
                              relu, stat_part)
-    if _decisions is not None and relu:
-        _decisions.append(("relu", gamma, z))
+    if _decisions["store"] is not None and relu:
+        _decisions["store"].append(("relu", gamma, z))
     return z
 
 
@@ -1110,8 +1109,8 @@ def conv_bn_act(x, w, cbias, gamma, beta, running_mean, running_var, residual=No
     if pending is not None:
         x._vspw_pending = None  # written by the GEMM just launched
         _fwd_apply["nodes"] += 1
-    if _decisions is not None and relu:
-        _decisions.append(("relu", gamma, out[0] if skip_out else out))
+    if _decisions["store"] is not None and relu:
+        _decisions["store"].append(("relu", gamma, out[0] if skip_out else out))
     if out_link is not None and out_link.y is not None:
         z = out[0] if skip_out else out
         z._vspw_link = out_link
@@ -1133,8 +1132,8 @@ class MaxPool3x3s2Fn(torch.autograd.Function):
         _C.call("vspw_maxpool3x3s2_fwd", _p(x), _p(y), _p(idx), n, h, w, c, oh, ow, _stream())
         ctx.shape = (n, c, h, w, oh, ow)
         ctx.save_for_backward(idx)
-        if _decisions is not None:
-            _decisions.append(("maxpool", None, idx))
+        if _decisions["store"] is not None:
+            _decisions["store"].append(("maxpool", None, idx))
         return y
 
     @staticmethod

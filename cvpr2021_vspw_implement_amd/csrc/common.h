@@ -29,6 +29,16 @@ static inline int vspw_stream_grid(long long work_items, int block) {
     return (int)g;
 }
 
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch, used for speed only); give every XCD a
+// contiguous range of tiles so that the N-tiles of one M-tile (same gathered pixels) and neighbouring M-tiles (shared
+// 3x3 halo rows) hit the same L2.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -117,15 +117,7 @@ __device__ __forceinline__ bool nt_src_coord(const IgemmNT& p, int by, int bx, i
     }
 }
 
-// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch, used for speed only); give every XCD a
-// contiguous range of tiles so that the N-tiles of one M-tile (same gathered pixels) and neighbouring M-tiles (shared
-// 3x3 halo rows) hit the same L2.  Bijective for any grid size.
-__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int q = nblocks >> 3, r = nblocks & 7;
-    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + idx;
-}
+// (workgroup -> tile order: xcd_remap, common.h)
 
 // WM x WN = MFMA 32x32 tiles per wave; 2x2 waves -> workgroup tile (64*WM) x (64*WN).
 template <int WM, int WN>

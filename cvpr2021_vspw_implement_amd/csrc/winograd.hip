@@ -193,7 +193,9 @@ static int wino_tb() {
     return (v == 8 || v == 16 || v == 32 || v == 64) ? v : 8;
 }
 
-template <bool FRONT>
+// ROWS: m holds the 8 half-transformed planes P [4][2][m_rows][K] of wino_rows.hip instead of the 16 planes of M
+// ([16][m_rows][K], m_rows = T): Y[i][j] = sum_a A^T[i][a] P[a][j].
+template <bool FRONT, bool ROWS>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restrict__ m, const float* __restrict__ bias,
                                                           float* __restrict__ y, const float* __restrict__ relu_src,
                                                           const float* __restrict__ bn_y,
@@ -201,14 +203,14 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
                                                           const float* __restrict__ bn_invstd,
                                                           float* __restrict__ stat_part,
                                                           const float* __restrict__ addend, int act, WinoGeom g, int K,
-                                                          int cl4, int WINO_TB, int ldy) {
+                                                          int cl4, int WINO_TB, int ldy, int m_rows) {
     __shared__ f32x4 red[2][256];
     const int tid = threadIdx.x;
     const int lane_c = tid % cl4, lane_t = tid / cl4;
     const int tpi_iter = 256 / cl4;  // tiles per iteration
     const int k = (blockIdx.y * cl4 + lane_c) * 4;
     const int t0 = blockIdx.x * WINO_TB;
-    const size_t plane = (size_t)g.T * K;
+    const size_t plane = (size_t)m_rows * K;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + k) : zero;
     f32x4 mu = zero, is = zero;
@@ -223,16 +225,24 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
         int img, sy, sx, ty, tx;
         wino_tile(g, t, img, sy, sx, ty, tx);
         const float* in = m + (size_t)t * K + k;
-        f32x4 mm[4][4];
+        f32x4 r[2][4];   // 16 planes: rows reduced, r[a][.]
+        f32x4 pp[4][2];  // ROWS: P[a][j]
+        if constexpr (ROWS) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) mm[i][j] = *reinterpret_cast<const f32x4*>(in + (size_t)(i * 4 + j) * plane);
-        f32x4 r[2][4];
+                for (int j = 0; j < 2; ++j) pp[i][j] = *reinterpret_cast<const f32x4*>(in + (size_t)(i * 2 + j) * plane);
+        } else {
+            f32x4 mm[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            r[0][j] = mm[0][j] + mm[1][j] + mm[2][j];
-            r[1][j] = mm[1][j] - mm[2][j] - mm[3][j];
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mm[i][j] = *reinterpret_cast<const f32x4*>(in + (size_t)(i * 4 + j) * plane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r[0][j] = mm[0][j] + mm[1][j] + mm[2][j];
+                r[1][j] = mm[1][j] - mm[2][j] - mm[3][j];
+            }
         }
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -241,7 +251,11 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
             for (int b = 0; b < 2; ++b) {
                 const int ox = (2 * tx + b) * g.d + sx;
                 if (oy >= g.h || ox >= g.w) continue;
-                f32x4 o = (b == 0 ? (r[a][0] + r[a][1] + r[a][2]) : (r[a][1] - r[a][2] - r[a][3])) + bv;
+                f32x4 o;
+                if constexpr (ROWS)
+                    o = (a == 0 ? (pp[0][b] + pp[1][b] + pp[2][b]) : (pp[1][b] - pp[2][b] - pp[3][b])) + bv;
+                else
+                    o = (b == 0 ? (r[a][0] + r[a][1] + r[a][2]) : (r[a][1] - r[a][2] - r[a][3])) + bv;
                 const size_t e = (((size_t)img * g.h + oy) * g.w + ox) * ldy + k;  // (ldy = K except vspw_wino_output_ex)
                 if (FRONT) {
                     const f32x4 z = *reinterpret_cast<const f32x4*>(relu_src + e);
@@ -408,11 +422,35 @@ extern "C" int vspw_wino_output(const vspw_conv_desc* d, const float* m, int cha
     const int tb = wino_tb();
     const dim3 grid(vspw_cdiv(g.T, tb), channels / 4 / cl4);
     if (front)
-        hipLaunchKernelGGL(wino_output_kernel<true>, grid, dim3(256), 0, vspw_stream(stream), m, bias, y, relu_src, bn_y,
-                           bn_mean, bn_invstd, stat_part, nullptr, 0, g, channels, cl4, tb, channels);
+        hipLaunchKernelGGL((wino_output_kernel<true, false>), grid, dim3(256), 0, vspw_stream(stream), m, bias, y, relu_src,
+                           bn_y, bn_mean, bn_invstd, stat_part, nullptr, 0, g, channels, cl4, tb, channels, g.T);
     else
-        hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(256), 0, vspw_stream(stream), m, bias, y, nullptr, nullptr,
-                           nullptr, nullptr, stat_part, addend, act, g, channels, cl4, tb, channels);
+        hipLaunchKernelGGL((wino_output_kernel<false, false>), grid, dim3(256), 0, vspw_stream(stream), m, bias, y, nullptr,
+                           nullptr, nullptr, nullptr, stat_part, addend, act, g, channels, cl4, tb, channels, g.T);
+    return vspw_launch_status();
+}
+
+// vspw_wino_output for the half-transformed planes of vspw_wino_gemm_rows / vspw_wino_gemm_fused_rows:
+// tp [4][2][tpad][channels], tpad = vspw_wino_rows_tpad(d, reduce channels, channels).
+extern "C" int vspw_wino_output_rows(const vspw_conv_desc* d, const float* tp, long long tpad, int channels,
+                                     const float* bias, float* y, const float* relu_src, const float* bn_y,
+                                     const float* bn_mean, const float* bn_invstd, float* stat_part, const float* addend,
+                                     int act, void* stream) {
+    WinoGeom g;
+    const int cl4 = wino_cl4(channels);
+    if (act != 0 && act != 1) return VSPW_EINVAL;
+    if (relu_src != nullptr && (addend != nullptr || act != 0)) return VSPW_EINVAL;
+    if (!wino_geom(d, g) || !tp || !y || cl4 == 0 || tpad < g.T || tpad > 0x3fffffffLL) return VSPW_EINVAL;
+    const bool front = relu_src != nullptr;
+    if (front && (!bn_y || !bn_mean || !bn_invstd || !stat_part)) return VSPW_EINVAL;
+    const int tb = wino_tb();
+    const dim3 grid(vspw_cdiv(g.T, tb), channels / 4 / cl4);
+    if (front)
+        hipLaunchKernelGGL((wino_output_kernel<true, true>), grid, dim3(256), 0, vspw_stream(stream), tp, bias, y, relu_src,
+                           bn_y, bn_mean, bn_invstd, stat_part, nullptr, 0, g, channels, cl4, tb, channels, (int)tpad);
+    else
+        hipLaunchKernelGGL((wino_output_kernel<false, true>), grid, dim3(256), 0, vspw_stream(stream), tp, bias, y, nullptr,
+                           nullptr, nullptr, nullptr, stat_part, addend, act, g, channels, cl4, tb, channels, (int)tpad);
     return vspw_launch_status();
 }
 
@@ -427,8 +465,8 @@ extern "C" int vspw_wino_output_ex(const vspw_conv_desc* d, const float* m, int 
         return VSPW_EINVAL;
     const int tb = wino_tb();
     const dim3 grid(vspw_cdiv(g.T, tb), channels / 4 / cl4);
-    hipLaunchKernelGGL(wino_output_kernel<false>, grid, dim3(256), 0, vspw_stream(stream), m, bias, y, nullptr, nullptr,
-                       nullptr, nullptr, nullptr, nullptr, act, g, channels, cl4, tb, (int)ldy);
+    hipLaunchKernelGGL((wino_output_kernel<false, false>), grid, dim3(256), 0, vspw_stream(stream), m, bias, y, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, act, g, channels, cl4, tb, (int)ldy, g.T);
     return vspw_launch_status();
 }
 

@@ -94,11 +94,11 @@ def _nn(*ptrs):
     return sum(1 for q in ptrs if q is not None)
 
 
-def _wino_bytes(a, chan_idx, streams_full, m_idx=None):
+def _wino_bytes(a, chan_idx, streams_full, m_idx=None, planes=16.0):
     d = a[0]._obj
     T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
     c = int(a[chan_idx])
-    return 4.0 * c * (16.0 * T + d.n * d.h * d.w * streams_full)
+    return 4.0 * c * (planes * T + d.n * d.h * d.w * streams_full)
 
 
 _HBM_BYTES = {
@@ -112,6 +112,8 @@ _HBM_BYTES = {
     "vspw_wino_dy": lambda a: _wino_bytes(a, 2, 1),
     # M -> y (+ relu_src / bn_y / addend operand streams when present)
     "vspw_wino_output": lambda a: _wino_bytes(a, 2, 1 + _nn(a[5], a[6], a[10])),
+    # P (8 planes) -> y
+    "vspw_wino_output_rows": lambda a: _wino_bytes(a, 3, 1 + _nn(a[6], a[7], a[11]), planes=8.0),
 }
 
 
@@ -202,7 +204,9 @@ _wino = {"enabled": os.environ.get("VSPW_WINOGRAD", "1") == "1", "min_c": int(os
          # weight gradient
          "fuse_fwd": os.environ.get("VSPW_WINO_FUSE_FWD", "0") == "1",
          "fuse_dgrad": os.environ.get("VSPW_WINO_FUSE_DGRAD", "1") == "1",
-         "fuse_max_rows": int(os.environ.get("VSPW_WINO_FUSE_MAXROWS", "512"))}
+         "fuse_max_rows": int(os.environ.get("VSPW_WINO_FUSE_MAXROWS", "512")),
+         # the four GEMMs of a transform row in one workgroup (csrc/wino_rows.hip) where the library expects it to win
+         "rows": os.environ.get("VSPW_WINO_ROWS", "1") == "1"}
 
 
 def set_winograd(enabled):
@@ -223,7 +227,6 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
     T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
     if u is None:
         u = _wino_weights(w, data_gradient)
-    m = torch.empty((16, T, rows), device=dev, dtype=torch.float32)
     v = None
     # measured (bench shapes): staging the transform costs the GEMM ~10 % (4 loads + 16 VALU per staged float4 on the
     # lanes fp32 MFMA shares), the separate transform pass costs time proportional to the INPUT only: fusing wins up
@@ -231,19 +234,35 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
     if fuse is None:
         fuse = _wino["fuse_dgrad"] if data_gradient else _wino["fuse_fwd"]
     fused = fuse and rows <= _wino["fuse_max_rows"]
+    # row-fused form (csrc/wino_rows.hip): the four GEMMs of a transform row in one workgroup, half of the output
+    # transform in its registers - the GEMM writes (and the output transform reads) 8 planes instead of 16
+    tpad = 0
+    if _wino["rows"] and _C.query("vspw_wino_rows_prefer", ctypes.byref(d), reduce_c, rows, 1 if fused else 0) == 1:
+        tpad = int(_C.query("vspw_wino_rows_tpad", ctypes.byref(d), reduce_c, rows, 1 if fused else 0))
+    m = torch.empty((8, tpad, rows) if tpad else (16, T, rows), device=dev, dtype=torch.float32)
     if fused:  # the input transform is evaluated by the GEMM while it stages its A operand: V is never written
         with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-winof"), _conv_flops(d)):
-            _C.call("vspw_wino_gemm_fused", ctypes.byref(d), _p(src), reduce_c, _p(u), rows, _p(m), st)
+            if tpad:
+                _C.call("vspw_wino_gemm_fused_rows", ctypes.byref(d), _p(src), reduce_c, _p(u), rows, _p(m), st)
+            else:
+                _C.call("vspw_wino_gemm_fused", ctypes.byref(d), _p(src), reduce_c, _p(u), rows, _p(m), st)
     else:
         v = torch.empty((16, T, reduce_c), device=dev, dtype=torch.float32)
         _C.call("vspw_wino_input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
         with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-wino"), _conv_flops(d)):
-            _C.call("vspw_bmm_nt", _p(v), _p(u), _p(m), 16, T, rows, reduce_c, st)
+            if tpad:
+                _C.call("vspw_wino_gemm_rows", ctypes.byref(d), _p(v), reduce_c, _p(u), rows, _p(m), st)
+            else:
+                _C.call("vspw_bmm_nt", _p(v), _p(u), _p(m), 16, T, rows, reduce_c, st)
     z = y_ = mean = invstd = None
     if front is not None:
         z, y_, mean, invstd = front
-    _C.call("vspw_wino_output", ctypes.byref(d), _p(m), rows, _p(bias), _p(dst), _p(z), _p(y_), _p(mean), _p(invstd),
-            _p(part), _p(addend), act, st)
+    if tpad:
+        _C.call("vspw_wino_output_rows", ctypes.byref(d), _p(m), tpad, rows, _p(bias), _p(dst), _p(z), _p(y_), _p(mean),
+                _p(invstd), _p(part), _p(addend), act, st)
+    else:
+        _C.call("vspw_wino_output", ctypes.byref(d), _p(m), rows, _p(bias), _p(dst), _p(z), _p(y_), _p(mean), _p(invstd),
+                _p(part), _p(addend), act, st)
     _wino["launches"] += 1
     return v
 

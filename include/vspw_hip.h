@@ -29,7 +29,7 @@ extern "C" {
 #define VSPW_EINVAL (-1)  /* bad argument / geometry / workspace too small */
 #define VSPW_ELAUNCH (-2) /* hipLaunchKernel reported an error */
 
-#define VSPW_ABI_VERSION 4
+#define VSPW_ABI_VERSION 5
 int vspw_abi_version(void);
 /* The hipError_t behind the most recent VSPW_ELAUNCH (0 if none) - for error messages. */
 int vspw_last_hip_error(void);
@@ -161,6 +161,28 @@ int vspw_wino_output_ex(const vspw_conv_desc* d, const float* m, int channels, c
 int vspw_wino_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
                      const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
                      float* stat_part, const float* addend, int act, void* stream);
+/* Row-fused form (wino_rows.hip): Y = A^T M A is separable, and the inner sum P[a][j] = sum_b M[a][b] A^T[j][b] mixes
+ * only the four positions of one transform row a.  One workgroup runs the four GEMMs of a row back to back and keeps the
+ * sum in registers: the GEMM writes the 8 planes P [4][2][tpad][rows] (half of M) and vspw_wino_output_rows finishes
+ * Y[i][j] = sum_a A^T[i][a] P[a][j] reading half as much.  tpad = vspw_wino_rows_tpad(d, channels, rows, fused) tiles
+ * per plane (T rounded up to the GEMM's tile height, which differs between the plain (fused = 0) and the fused-operand
+ * (fused = 1) GEMM; 0 = geometry not supported: rows % 128, channels % 32, 32-bit spans).
+ * vspw_wino_gemm_rows takes V = vspw_wino_input(..) [16][T][channels]; vspw_wino_gemm_fused_rows evaluates it from the
+ * NHWC tensor src like vspw_wino_gemm_fused.  Same reference call sites as vspw_wino_output. */
+long long vspw_wino_rows_tpad(const vspw_conv_desc* d, int channels, int rows, int fused);
+/* 1 when the row-fused form is expected to be the faster one for this geometry (enough workgroups to fill the chip,
+ * reduction short enough for the halved M traffic to matter): the dispatch rule callers use. */
+int vspw_wino_rows_prefer(const vspw_conv_desc* d, int channels, int rows, int fused);
+/* Tuning knob (experiments): force the GEMM tile of the row-fused form - 12 (64x128), 31 (96x128), 22 (128x128); 0 =
+ * automatic.  Changes vspw_wino_rows_tpad: set it before sizing buffers. */
+int vspw_wino_rows_config(int tile);
+int vspw_wino_gemm_rows(const vspw_conv_desc* d, const float* v, int channels, const float* u, int rows, float* tp,
+                        void* stream);
+int vspw_wino_gemm_fused_rows(const vspw_conv_desc* d, const float* src, int channels, const float* u, int rows,
+                              float* tp, void* stream);
+int vspw_wino_output_rows(const vspw_conv_desc* d, const float* tp, long long tpad, int channels, const float* bias,
+                          float* y, const float* relu_src, const float* bn_y, const float* bn_mean,
+                          const float* bn_invstd, float* stat_part, const float* addend, int act, void* stream);
 /* Weight gradient in the transform domain: dM = vspw_wino_dy(dY) [16][T][Cout]; dU = vspw_bmm_tn(dM, V, batch 16)
  * [16][Cout][Cin] with V = vspw_wino_input(x); dW = vspw_wino_dw(dU) in the weight layout [Cout][3][3][Cin]. */
 int vspw_wino_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream);

@@ -1,6 +1,8 @@
 """Kernel-level parity: every HIP kernel (called through the C ABI via ops.py) against a plain PyTorch fp32 CPU
 evaluation of the ATen op it replaces, forward and backward, on seeded inputs incl. ragged / odd sizes.
 Tolerances: fp32 kernels with different summation order -> rtol 1e-4 / atol scaled to the reduction length."""
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -66,8 +68,34 @@ def test_conv2d_fwd_bwd(dev, case):
         _close(bd.grad, br.grad, 1e-5, "conv bias grad %s" % (case,))
 
 
+@pytest.fixture
+def wino_rows_tile(request):
+    """Force the row-fused Winograd GEMM (csrc/wino_rows.hip) with the given tile: the library's own dispatch rule only
+    takes it for grids that fill the chip, which unit-test shapes never do."""
+    from cvpr2021_vspw_implement_amd import _C
+
+    _C.call("vspw_wino_rows_config", int(request.param))
+    yield int(request.param)
+    _C.call("vspw_wino_rows_config", 0)
+
+
+@pytest.mark.parametrize("wino_rows_tile", [12, 31, 22], indirect=True)
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[5] == 3 and c[6] == 1 and min(c[1], c[4]) >= 128])
+def test_conv2d_winograd_row_fused_form(dev, case, wino_rows_tile):
+    """The same parity gate as test_conv2d_fwd_bwd (against F.conv2d on the CPU) with the four GEMMs of a transform row
+    fused into one workgroup: plain V operand (forward), fused operand (data gradient), every tile height, ragged tile
+    counts (padded P planes), dilation sub-grids."""
+    from cvpr2021_vspw_implement_amd import _C, ops
+
+    n, c, h, w, k, ks, s, p, d, bias = case
+    dsc = ops._conv_desc(torch.empty(n, c, h, w, device="meta"), k, ks, ks, s, p, d)
+    assert _C.query("vspw_wino_rows_prefer", ctypes.byref(dsc), c, k, 0) == 1
+    test_conv2d_fwd_bwd(dev, case)
+
+
+@pytest.mark.parametrize("wino_rows_tile", [0, 12, 31], indirect=True)
 @pytest.mark.parametrize("dil,h,w", [(1, 12, 13), (2, 14, 14), (4, 15, 15)])
-def test_winograd_path_equals_direct_path_in_a_fused_chain(dev, dil, h, w):
+def test_winograd_path_equals_direct_path_in_a_fused_chain(dev, dil, h, w, wino_rows_tile):
     """1x1 conv+BN+ReLU -> 3x3 conv+BN+ReLU (fuse_input: the 3x3 data gradient carries the first node's BatchNorm-backward
     front end) -> sum of squares: outputs, batch statistics (taken from the output transform's partial sums) and every
     gradient with the Winograd path against the direct implicit GEMM.  Both are float32 evaluations of the same

@@ -136,8 +136,14 @@ __global__ __launch_bounds__(256) void wino_weight_multi_kernel(const vspw_wt_en
 
 // ------------------------------------------------------------------------------------------------ input
 // V[xi][t][c] = (B^T d B)[xi],  B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,1,0,-1]].  One thread: one tile, 4 channels.
+// APPLY: x has not been written yet - it is relu(scale * y + shift) of the conv+BN+ReLU node that produces this
+// convolution's input (its BatchNorm apply deferred into its one reader, ops._fwd_apply): the patch is evaluated from y
+// (same expression tree as bn_apply_kernel: bit-identical values; padding stays zero) and the tile's own 2x2 pixels -
+// every pixel belongs to exactly one tile - are written to zout for the backward pass.
+template <bool APPLY>
 __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ v, WinoGeom g,
-                                                         int C) {
+                                                         int C, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ zout) {
     const int c4n = C >> 2;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long long)g.T * c4n) return;
@@ -146,6 +152,11 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
     int img, sy, sx, ty, tx;
     wino_tile(g, t, img, sy, sx, ty, tx);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 sc = zero, sh = zero;
+    if (APPLY) {
+        sc = *reinterpret_cast<const f32x4*>(scale + c);
+        sh = *reinterpret_cast<const f32x4*>(shift + c);
+    }
     f32x4 dd[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -157,7 +168,16 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float* __restrict
             const int gx = 2 * tx - 1 + j;
             const int px = gx * g.d + sx;
             const bool ok = oky & (gx >= 0) & (px < g.w);
-            dd[i][j] = ok ? *reinterpret_cast<const f32x4*>(x + (((size_t)img * g.h + py) * g.w + px) * C + c) : zero;
+            const size_t e = (((size_t)img * g.h + py) * g.w + px) * C + c;
+            f32x4 val = ok ? *reinterpret_cast<const f32x4*>(x + e) : zero;
+            if (APPLY) {
+                val = val * sc + sh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) val[q] = val[q] > 0.f ? val[q] : 0.f;
+                if (!ok) val = zero;
+                if (ok && (i == 1 || i == 2) && (j == 1 || j == 2)) *reinterpret_cast<f32x4*>(zout + e) = val;
+            }
+            dd[i][j] = val;
         }
     }
     f32x4 r[4][4];
@@ -404,8 +424,21 @@ extern "C" int vspw_wino_input(const vspw_conv_desc* d, const float* x, int chan
     WinoGeom g;
     if (!wino_geom(d, g) || !x || !v || channels <= 0 || channels % 4) return VSPW_EINVAL;
     const long long items = (long long)g.T * (channels / 4);
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), x, v, g,
-                       channels);
+    hipLaunchKernelGGL(wino_input_kernel<false>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream),
+                       x, v, g, channels, nullptr, nullptr, nullptr);
+    return vspw_launch_status();
+}
+
+// vspw_wino_input of z = relu(scale * y + shift), which has NOT been materialised (the producing conv+BN+ReLU node
+// deferred its apply, cf. vspw_conv2d_fwd_apply): V from y, and z written to z_out for the node's other readers (the
+// backward pass).  scale_shift [2][channels].
+extern "C" int vspw_wino_input_apply(const vspw_conv_desc* d, const float* y, const float* scale_shift, float* z_out,
+                                     int channels, float* v, void* stream) {
+    WinoGeom g;
+    if (!wino_geom(d, g) || !y || !scale_shift || !z_out || !v || channels <= 0 || channels % 4) return VSPW_EINVAL;
+    const long long items = (long long)g.T * (channels / 4);
+    hipLaunchKernelGGL(wino_input_kernel<true>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream),
+                       y, v, g, channels, scale_shift, scale_shift + channels, z_out);
     return vspw_launch_status();
 }
 

@@ -32,6 +32,10 @@ def _residual_branch(block, x):
 # +-0 on the bench step (102.51 vs 102.58 ms: the 19 us bn_apply pass it removes costs as much as the 8-fold
 # re-evaluation in conv3's eight column tiles), so it is off by default; bit-identical either way (tests).
 _DEFER_CONV2 = os.environ.get("VSPW_FWD_APPLY_CONV2", "0") == "1"
+# conv1's BatchNorm apply + ReLU evaluated by conv2's Winograd input transform (ops._wino_takes_pending; anything else
+# that conv2 turns out to be materialises it first).  Measured on the bench step: +-0 (83.2-83.4 ms either way - the
+# transform, which touches every pixel four times, slows down by what the 20 us apply pass cost): off by default
+_DEFER_CONV1 = os.environ.get("VSPW_FWD_APPLY_CONV1", "0") == "1"
 
 
 class _BlockSequential(nn.Sequential):
@@ -97,9 +101,10 @@ class Bottleneck(nn.Module):
         # data-gradient epilogue instead of by a separate accumulation pass over the block input
         skip = x
         if x.requires_grad and torch.is_grad_enabled():
-            out, skip = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True, skip_out=True, fuse_input=sole_consumer)
+            out, skip = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True, skip_out=True, fuse_input=sole_consumer,
+                                        defer_apply=_DEFER_CONV1)
         else:
-            out = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True)
+            out = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True, defer_apply=_DEFER_CONV1)
         # conv1's output is only read by conv2, conv2's only by conv3 (pointwise: it may evaluate bn2 + ReLU itself)
         out = vnn.conv_bn_act(out, self.conv2, self.bn2, relu=True, fuse_input=True, defer_apply=_DEFER_CONV2)
         return vnn.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=_residual_branch(self, skip),

@@ -109,6 +109,8 @@ _HBM_BYTES = {
     "vspw_bn_bwd_reduce_pg": lambda a: 4.0 * a[6] * a[7] * _nn(a[0], a[1], a[2]),
     "vspw_bn_stats": lambda a: 4.0 * a[1] * a[2],
     "vspw_wino_input": lambda a: _wino_bytes(a, 2, 1),
+    # y -> V, z
+    "vspw_wino_input_apply": lambda a: _wino_bytes(a, 4, 2),
     "vspw_wino_dy": lambda a: _wino_bytes(a, 2, 1),
     # M -> y (+ relu_src / bn_y / addend operand streams when present)
     "vspw_wino_output": lambda a: _wino_bytes(a, 2, 1 + _nn(a[5], a[6], a[10])),
@@ -219,9 +221,10 @@ def _wino_ok(d):
 
 
 def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, part=None, what="fwd", u=None,
-               addend=None, act=0, fuse=None):
+               addend=None, act=0, fuse=None, pending=None):
     """dst = conv(src) through U, V, M (see winograd.hip); rows = output channels, reduce_c = channels of src.
-    u: transformed weights supplied by the caller (inference: of the BatchNorm-folded weights)."""
+    u: transformed weights supplied by the caller (inference: of the BatchNorm-folded weights).
+    pending = (y_prev, scale_shift): src has not been written - the input transform evaluates it (see _fwd_apply)."""
     dev = src.device
     st = _stream()
     T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
@@ -234,6 +237,8 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
     if fuse is None:
         fuse = _wino["fuse_dgrad"] if data_gradient else _wino["fuse_fwd"]
     fused = fuse and rows <= _wino["fuse_max_rows"]
+    if pending is not None and fused:
+        raise RuntimeError("deferred input + fused Winograd operand (see _wino_takes_pending)")
     # row-fused form (csrc/wino_rows.hip): the four GEMMs of a transform row in one workgroup, half of the output
     # transform in its registers - the GEMM writes (and the output transform reads) 8 planes instead of 16
     tpad = 0
@@ -248,7 +253,10 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
                 _C.call("vspw_wino_gemm_fused", ctypes.byref(d), _p(src), reduce_c, _p(u), rows, _p(m), st)
     else:
         v = torch.empty((16, T, reduce_c), device=dev, dtype=torch.float32)
-        _C.call("vspw_wino_input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
+        if pending is not None:
+            _C.call("vspw_wino_input_apply", ctypes.byref(d), _p(pending[0]), _p(pending[1]), _p(src), reduce_c, _p(v), st)
+        else:
+            _C.call("vspw_wino_input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
         with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-wino"), _conv_flops(d)):
             if tpad:
                 _C.call("vspw_wino_gemm_rows", ctypes.byref(d), _p(v), reduce_c, _p(u), rows, _p(m), st)
@@ -267,6 +275,14 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
     return v
 
 
+def _wino_takes_pending(d, pending, wgrad):
+    """A deferred input (see _fwd_apply) can be evaluated by the Winograd input transform when that transform is a pass
+    of its own (V kept for the weight gradient; the fused-operand GEMM reads every pixel four times per position) and
+    the deferred node has no residual branch."""
+    return (_fwd_apply["wino"] and pending[2] is None and _wino["keep_v"] and bool(wgrad) and _wino["wgrad"]
+            and not _wino["fuse_fwd"] and d.c % 4 == 0)
+
+
 def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None, wgrad=True):
     """x NHWC-memory [N,C,H,W]; w [K,C,KH,KW] in channels_last memory ([K][KH][KW][C]).
     pending = (y_prev, scale_shift, residual): x has not been written yet - it is relu(scale*y_prev + shift +
@@ -282,7 +298,7 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None,
     d = _conv_desc(x, k, kh, kw, stride, pad, dil)
     y = empty_nhwc(d.n, k, d.oh, d.ow, x.device)
     part = None
-    if pending is None and _wino_ok(d):
+    if _wino_ok(d) and (pending is None or _wino_takes_pending(d, pending, wgrad)):
         if want_stats:
             part = torch.empty((_C.query("vspw_wino_stat_partials", ctypes.byref(d)), 2, k), device=x.device,
                                dtype=torch.float32)
@@ -290,7 +306,8 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None,
         # only when there will be one: frozen weights / no_grad evaluation take the GEMM that transforms its A operand
         # itself (V, four times the size of x, is then never written)
         needs_v = _wino["keep_v"] and bool(wgrad) and _wino["wgrad"]
-        v = _wino_conv(d, x, w, k, c, False, bias, y, part=part, fuse=None if needs_v else True)
+        v = _wino_conv(d, x, w, k, c, False, bias, y, part=part, fuse=None if needs_v else True,
+                       pending=None if pending is None else (pending[0], pending[1]))
         if needs_v and v is not None:
             y._vspw_wino_v = v  # picked up (and removed) by the autograd node that called us
         return y, part, d
@@ -909,7 +926,9 @@ _bn_fusion = {"enabled": os.environ.get("VSPW_NO_BN_FUSION", "0") != "1", "fused
 # one next reader - a pointwise conv - leaves z unwritten and hands (y, scale/shift, residual) to that conv, whose GEMM
 # evaluates z while staging its A operand and writes it for everyone else (vspw_conv2d_fwd_apply).  Saves the separate
 # read-read-write pass of vspw_bn_apply plus the GEMM's own read of z.
-_fwd_apply = {"enabled": os.environ.get("VSPW_NO_FWD_APPLY", "0") != "1", "nodes": 0}
+_fwd_apply = {"enabled": os.environ.get("VSPW_NO_FWD_APPLY", "0") != "1", "nodes": 0,
+              # ... and into the input transform of a Winograd 3x3 reader (conv1 -> conv2 of a bottleneck)
+              "wino": os.environ.get("VSPW_NO_FWD_APPLY_WINO", "0") != "1", "wino_nodes": 0}
 
 
 def materialize(x):
@@ -1117,6 +1136,12 @@ def conv_bn_act(x, w, cbias, gamma, beta, running_mean, running_var, residual=No
         if ok:
             ok = _C.query("vspw_conv2d_fwd_apply_supported",
                           ctypes.byref(_conv_desc(x, w.shape[0], 1, 1, stride, pad, dil))) == 1
+        elif fuse_input and is_nhwc(x) and w.shape[2] == 3 and w.shape[3] == 3:
+            # stride-1 3x3 on the Winograd path: its input transform evaluates the deferred apply
+            dq = _conv_desc(x, w.shape[0], 3, 3, stride, pad, dil)
+            ok = _wino_ok(dq) and _wino_takes_pending(dq, pending, torch.is_grad_enabled() and w.requires_grad)
+            if ok:
+                _fwd_apply["wino_nodes"] += 1
         if not ok:
             materialize(x)
             pending = None

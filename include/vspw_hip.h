@@ -147,6 +147,13 @@ int vspw_wino_weights(const float* w, float* u, int k, int c, int data_gradient,
 long long vspw_wino_weight_tiles(int k, int c);
 int vspw_wino_weights_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream);
 int vspw_wino_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream);
+/* vspw_wino_input of z = relu(scale*y + shift) - the BatchNorm apply + ReLU of the conv+BN+ReLU node that produces this
+ * convolution's input (models/resnet.py:76-78 followed by conv2, :79) - which has NOT been materialised: V is evaluated
+ * from y (same expression tree as vspw_bn_apply: bit-identical z; padding stays zero) and z is written to z_out for the
+ * backward pass.  scale_shift [2][channels].  One pass over y instead of vspw_bn_apply's read-write followed by the
+ * transform's read. */
+int vspw_wino_input_apply(const vspw_conv_desc* d, const float* y, const float* scale_shift, float* z_out, int channels,
+                          float* v, void* stream);
 /* vspw_wino_input + vspw_bmm_nt in one launch: the input transform is evaluated while the GEMM stages its A operand
  * (V is never written).  src = x or dY (NHWC, `channels`), u [16][rows][channels], m [16][T][rows]. */
 int vspw_wino_gemm_fused(const vspw_conv_desc* d, const float* src, int channels, const float* u, int rows, float* m,

@@ -206,6 +206,57 @@ def test_block_output_evaluated_by_the_next_conv1(dev, n, cm, c, h, w, k, fused)
         _close(got.grad, want.grad, 5e-4, what)
 
 
+@pytest.mark.parametrize("dil,h,w,c1", [(2, 13, 14, 128), (1, 9, 11, 256), (4, 15, 15, 128)])
+def test_conv1_apply_evaluated_by_the_winograd_input_transform(dev, dil, h, w, c1):
+    """relu(bn1(conv1(x))) left to conv2's Winograd input transform (models/resnet.py:76-79, vspw_wino_input_apply): the
+    deferred and the materialised evaluation are the same float32 expression - every output and gradient BIT-identical -
+    and both match autograd on the plain composition; ragged dilation sub-grids, padding taps stay zero."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(1)  # (seed 9 at dil 4 holds a pre-ReLU value of 6e-9: a coin toss in any float32)
+    n, c0, c2 = 2, 64, 128
+    x = torch.randn(n, c0, h, w, generator=g)
+    w1 = torch.randn(c1, c0, 1, 1, generator=g) * (2.0 / c0) ** 0.5
+    w2 = torch.randn(c2, c1, 3, 3, generator=g) * (2.0 / (9 * c1)) ** 0.5
+    g1, b1 = torch.rand(c1, generator=g) + 0.5, torch.randn(c1, generator=g) * 0.3
+    g2, b2 = torch.rand(c2, generator=g) + 0.5, torch.randn(c2, generator=g) * 0.1
+    go = torch.randn(n, c2, h, w, generator=g)
+    ref = [t.clone().requires_grad_(True) for t in (x, w1, w2)]
+    a = F.relu(F.batch_norm(F.conv2d(ref[0], ref[1]), None, None, g1, b1, True, 0.1, 1e-5))
+    o = F.relu(F.batch_norm(F.conv2d(a, ref[2], padding=dil, dilation=dil), None, None, g2, b2, True, 0.1, 1e-5))
+    o.backward(go)
+    res = []
+    for deferred in (False, True):
+        ops._fwd_apply["wino"] = deferred
+        try:
+            dv = [x.to(dev).requires_grad_(True),
+                  w1.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True),
+                  w2.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)]
+            stats = lambda ch: (torch.zeros(ch, device=dev), torch.ones(ch, device=dev))  # noqa: E731
+            before = ops._fwd_apply["wino_nodes"]
+            ad = ops.conv_bn_act(dv[0], dv[1], None, g1.to(dev), b1.to(dev), *stats(c1), training=True, relu=True,
+                                 defer_apply=True)
+            assert getattr(ad, "_vspw_pending", None) is not None
+            od = ops.conv_bn_act(ad, dv[2], None, g2.to(dev), b2.to(dev), *stats(c2), stride=1, pad=dil, dil=dil,
+                                 training=True, relu=True, fuse_input=True)
+            assert getattr(ad, "_vspw_pending", None) is None
+            assert ops._fwd_apply["wino_nodes"] - before == (1 if deferred else 0)
+            od.backward(go.to(dev))
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            res.append([t.detach().cpu() for t in (ad, od, dv[0].grad, dv[1].grad, dv[2].grad)])
+        finally:
+            ops._fwd_apply["wino"] = True
+    names = ("conv1 node output", "conv2 node output", "d x", "d w1", "d w2")
+    for nm, p_, q_ in zip(names, res[0], res[1]):
+        assert torch.equal(p_, q_), nm
+    _close(res[1][0], a, 1e-4, "conv1 node output")
+    _close(res[1][1], o, 3e-4, "conv2 node output")
+    for got, want, what in zip(res[1][2:], ref, ("d x", "d w1", "d w2")):
+        err = float((got - want.grad).norm() / want.grad.norm())
+        assert err < 2e-5, (what, err)
+
+
 @pytest.mark.parametrize("shape,relu,res,train", [
     ((4, 64, 9, 11), True, False, True),
     ((2, 256, 7, 5), True, True, True),

@@ -1,0 +1,475 @@
+"""Convolution operators of the hot path (see ops.py): forward / data gradient / weight gradient through the implicit
+GEMM and Winograd kernels, the derived-weight caches, the weight-gradient side stream and the plain conv2d node."""
+import ctypes
+import os
+
+import torch
+
+from . import _C
+from ._C import ConvDesc
+from ._opbase import (_Timed, _conv_desc, _conv_flops, _conv_tag, _ktimer, _p, _require_gpu, _stream, _ws, empty_nhwc,
+                      is_nhwc, to_nhwc)
+
+# --------------------------------------------------------------------------------------------------- conv
+# Forward apply deferred into the consumer (residual blocks): a conv+BN+residual+ReLU node whose output z has exactly
+# one next reader - a pointwise conv - leaves z unwritten and hands (y, scale/shift, residual) to that conv, whose GEMM
+# evaluates z while staging its A operand and writes it for everyone else (vspw_conv2d_fwd_apply).  Saves the separate
+# read-read-write pass of vspw_bn_apply plus the GEMM's own read of z.
+_fwd_apply = {"enabled": os.environ.get("VSPW_NO_FWD_APPLY", "0") != "1", "nodes": 0,
+              # ... and into the input transform of a Winograd 3x3 reader (conv1 -> conv2 of a bottleneck)
+              "wino": os.environ.get("VSPW_NO_FWD_APPLY_WINO", "0") != "1", "wino_nodes": 0}
+
+
+# Winograd F(2x2,3x3) for stride-1 3x3 convolutions, forward and data gradient (csrc/winograd.hip): 4/9 of the direct
+# multiplications, run by the pointwise MFMA kernel as 16 batched GEMMs.  VSPW_WINOGRAD=0 switches back to the direct
+# implicit GEMM; VSPW_WINO_MINC = smallest channel count (both sides) that takes this path.
+_wino = {"enabled": os.environ.get("VSPW_WINOGRAD", "1") == "1", "min_c": int(os.environ.get("VSPW_WINO_MINC", "128")),
+         "wgrad": os.environ.get("VSPW_WINO_WGRAD", "1") == "1", "launches": 0,
+         "keep_v": os.environ.get("VSPW_WINO_KEEP_V", "1") == "1",
+         # the GEMM evaluates the input transform itself (vspw_wino_gemm_fused); forward: off, its V is reused by the
+         # weight gradient
+         "fuse_fwd": os.environ.get("VSPW_WINO_FUSE_FWD", "0") == "1",
+         "fuse_dgrad": os.environ.get("VSPW_WINO_FUSE_DGRAD", "1") == "1",
+         "fuse_max_rows": int(os.environ.get("VSPW_WINO_FUSE_MAXROWS", "512")),
+         # the four GEMMs of a transform row in one workgroup (csrc/wino_rows.hip) where the library expects it to win
+         "rows": os.environ.get("VSPW_WINO_ROWS", "1") == "1"}
+
+
+def set_winograd(enabled):
+    _wino["enabled"] = bool(enabled)
+
+
+def _wino_ok(d):
+    return (_wino["enabled"] and d.kh == 3 and d.kw == 3 and d.stride == 1 and min(d.c, d.k) >= _wino["min_c"]
+            and _C.query("vspw_wino_supported", ctypes.byref(d)) == 1)
+
+
+def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, part=None, what="fwd", u=None,
+               addend=None, act=0, fuse=None, pending=None):
+    """dst = conv(src) through U, V, M (see winograd.hip); rows = output channels, reduce_c = channels of src.
+    u: transformed weights supplied by the caller (inference: of the BatchNorm-folded weights).
+    pending = (y_prev, scale_shift): src has not been written - the input transform evaluates it (see _fwd_apply)."""
+    dev = src.device
+    st = _stream()
+    T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
+    if u is None:
+        u = _wino_weights(w, data_gradient)
+    v = None
+    # measured (bench shapes): staging the transform costs the GEMM ~10 % (4 loads + 16 VALU per staged float4 on the
+    # lanes fp32 MFMA shares), the separate transform pass costs time proportional to the INPUT only: fusing wins up
+    # to 512 output rows (256->256: -31 us per launch) and loses beyond (512->1024, 512->4096)
+    if fuse is None:
+        fuse = _wino["fuse_dgrad"] if data_gradient else _wino["fuse_fwd"]
+    fused = fuse and rows <= _wino["fuse_max_rows"]
+    if pending is not None and fused:
+        raise RuntimeError("deferred input + fused Winograd operand (see _wino_takes_pending)")
+    # row-fused form (csrc/wino_rows.hip): the four GEMMs of a transform row in one workgroup, half of the output
+    # transform in its registers - the GEMM writes (and the output transform reads) 8 planes instead of 16
+    tpad = 0
+    if _wino["rows"] and _C.query("vspw_wino_rows_prefer", ctypes.byref(d), reduce_c, rows, 1 if fused else 0) == 1:
+        tpad = int(_C.query("vspw_wino_rows_tpad", ctypes.byref(d), reduce_c, rows, 1 if fused else 0))
+    m = torch.empty((8, tpad, rows) if tpad else (16, T, rows), device=dev, dtype=torch.float32)
+    if fused:  # the input transform is evaluated by the GEMM while it stages its A operand: V is never written
+        with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-winof"), _conv_flops(d)):
+            if tpad:
+                _C.call("vspw_wino_gemm_fused_rows", ctypes.byref(d), _p(src), reduce_c, _p(u), rows, _p(m), st)
+            else:
+                _C.call("vspw_wino_gemm_fused", ctypes.byref(d), _p(src), reduce_c, _p(u), rows, _p(m), st)
+    else:
+        v = torch.empty((16, T, reduce_c), device=dev, dtype=torch.float32)
+        if pending is not None:
+            _C.call("vspw_wino_input_apply", ctypes.byref(d), _p(pending[0]), _p(pending[1]), _p(src), reduce_c, _p(v), st)
+        else:
+            _C.call("vspw_wino_input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
+        with _Timed("igemm_nt_kernel", 2.0 * 16 * T * rows * reduce_c, _conv_tag(d, what + "-wino"), _conv_flops(d)):
+            if tpad:
+                _C.call("vspw_wino_gemm_rows", ctypes.byref(d), _p(v), reduce_c, _p(u), rows, _p(m), st)
+            else:
+                _C.call("vspw_bmm_nt", _p(v), _p(u), _p(m), 16, T, rows, reduce_c, st)
+    z = y_ = mean = invstd = None
+    if front is not None:
+        z, y_, mean, invstd = front
+    if tpad:
+        _C.call("vspw_wino_output_rows", ctypes.byref(d), _p(m), tpad, rows, _p(bias), _p(dst), _p(z), _p(y_), _p(mean),
+                _p(invstd), _p(part), _p(addend), act, st)
+    else:
+        _C.call("vspw_wino_output", ctypes.byref(d), _p(m), rows, _p(bias), _p(dst), _p(z), _p(y_), _p(mean), _p(invstd),
+                _p(part), _p(addend), act, st)
+    _wino["launches"] += 1
+    return v
+
+
+def _wino_takes_pending(d, pending, wgrad):
+    """A deferred input (see _fwd_apply) can be evaluated by the Winograd input transform when that transform is a pass
+    of its own (V kept for the weight gradient; the fused-operand GEMM reads every pixel four times per position) and
+    the deferred node has no residual branch."""
+    return (_fwd_apply["wino"] and pending[2] is None and _wino["keep_v"] and bool(wgrad) and _wino["wgrad"]
+            and not _wino["fuse_fwd"] and d.c % 4 == 0)
+
+
+def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None, wgrad=True):
+    """x NHWC-memory [N,C,H,W]; w [K,C,KH,KW] in channels_last memory ([K][KH][KW][C]).
+    pending = (y_prev, scale_shift, residual): x has not been written yet - it is relu(scale*y_prev + shift +
+    residual) of the node that produced it; this (pointwise) GEMM evaluates it while staging and fills x.
+    wgrad: a weight gradient will be asked for (the autograd node's needs_input_grad of w)."""
+    _require_gpu(x, "conv2d")
+    x = to_nhwc(x)
+    if not is_nhwc(w):
+        w = w.contiguous(memory_format=torch.channels_last)
+    k, c, kh, kw = w.shape
+    if c != x.shape[1]:
+        raise RuntimeError("conv2d: input has %d channels, weight expects %d" % (x.shape[1], c))
+    d = _conv_desc(x, k, kh, kw, stride, pad, dil)
+    y = empty_nhwc(d.n, k, d.oh, d.ow, x.device)
+    part = None
+    if _wino_ok(d) and (pending is None or _wino_takes_pending(d, pending, wgrad)):
+        if want_stats:
+            part = torch.empty((_C.query("vspw_wino_stat_partials", ctypes.byref(d)), 2, k), device=x.device,
+                               dtype=torch.float32)
+        # the input transform is kept for this convolution's weight gradient (same V: saves its recomputation there) -
+        # only when there will be one: frozen weights / no_grad evaluation take the GEMM that transforms its A operand
+        # itself (V, four times the size of x, is then never written)
+        needs_v = _wino["keep_v"] and bool(wgrad) and _wino["wgrad"]
+        v = _wino_conv(d, x, w, k, c, False, bias, y, part=part, fuse=None if needs_v else True,
+                       pending=None if pending is None else (pending[0], pending[1]))
+        if needs_v and v is not None:
+            y._vspw_wino_v = v  # picked up (and removed) by the autograd node that called us
+        return y, part, d
+    if want_stats:
+        tiles = _C.query("vspw_conv2d_stats_partials", ctypes.byref(d))
+        part = torch.empty((tiles, 2, k), device=x.device, dtype=torch.float32)
+    with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "fwd")):
+        if pending is not None:
+            py, pss, pres = pending
+            _C.call("vspw_conv2d_fwd_apply", ctypes.byref(d), _p(py), _p(pres), _p(pss), _p(x), _p(w), _p(bias), _p(y),
+                    _p(part), _stream())
+        else:
+            _C.call("vspw_conv2d_fwd", ctypes.byref(d), _p(x), _p(w), _p(bias), _p(y), _p(part), _stream())
+    return y, part, d
+
+
+_wt_cache = {"gen": 0}  # generation counter shared by every derived-weight cache (see invalidate_inference_cache)
+_WT_ENTRY = None
+
+
+def _wt_key(w):
+    return (w.data_ptr(), w._version, _wt_cache["gen"], tuple(w.shape))
+
+
+class _DerivedWeights(object):
+    """Per-step cache of tensors derived from convolution weights (the [Cin][taps][Cout] copies of the data-gradient
+    GEMMs; the Winograd transforms).  Weights change once per step (the optimizer), so the derived tensors are
+    refreshed once per step - ALL of them by one multi-tensor launch over a device table (struct vspw_wt_entry),
+    triggered by the first use that finds its entry stale - instead of one small launch per layer inside the critical
+    path.  alloc(w) -> buffer; single(w, buf, stream); multi = C entry point taking (table, n, tiles, stream);
+    tiles(k, c, kh, kw) -> workgroups of one tensor in the multi launch."""
+
+    def __init__(self, alloc, single, multi, tiles):
+        self.alloc, self.single, self.multi, self.tiles = alloc, single, multi, tiles
+        self.clear()
+
+    def clear(self):
+        self.entries, self.order, self.table, self.table_n, self.total = {}, [], None, 0, 0
+
+    def _upload(self, device):
+        import numpy as np
+
+        global _WT_ENTRY
+        if _WT_ENTRY is None:  # struct vspw_wt_entry (include/vspw_hip.h)
+            _WT_ENTRY = np.dtype([("w", "<u8"), ("wT", "<u8"), ("tile0", "<i8"), ("k", "<i4"), ("taps", "<i4"),
+                                  ("c", "<i4"), ("reserved", "<i4")])
+        ents = [self.entries[i] for i in self.order]
+        rec = np.zeros(len(ents), dtype=_WT_ENTRY)
+        t0 = 0
+        for i, e in enumerate(ents):
+            k, c, kh, kw = e["shape"]
+            rec[i] = (e["ptr"], e["buf"].data_ptr(), t0, k, kh * kw, c, 0)
+            t0 += int(self.tiles(k, c, kh, kw))
+        self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
+        self.table_n = len(ents)
+        self.total = t0
+
+    def get(self, w):
+        import weakref
+
+        ents = self.entries
+        ident = (w.data_ptr(), tuple(w.shape))
+        e = ents.get(ident)
+        key = _wt_key(w)
+        if e is not None and e["ref"]() is None:
+            # the tensor this entry was made for is gone: its storage may have been freed and handed to ANOTHER weight
+            # with the same address / shape / version, so nothing cached under this identity can be trusted
+            del ents[ident]
+            self.order = [i for i in self.order if i != ident]
+            self.table = None
+            e = None
+        if e is not None and e["key"] == key:
+            return e["buf"]
+        capturing = torch.cuda.is_current_stream_capturing()
+        if e is None:
+            # first sight of this weight: own launch now, member of the batched refresh from the next step on
+            buf = self.alloc(w)
+            if capturing:  # a buffer from the graph's private pool must not leak into the eager cache
+                self.single(w, buf, _stream())
+                return buf
+            ents[ident] = e = {"buf": buf, "ptr": w.data_ptr(), "shape": tuple(w.shape), "key": None,
+                               "ref": weakref.ref(w)}
+            self.order.append(ident)
+            self.table = None
+        if not capturing:
+            dead = [i for i, x in ents.items() if x["ref"]() is None]
+            if dead:  # weights of a model that no longer exists
+                for i in dead:
+                    del ents[i]
+                self.order = [i for i in self.order if i in ents]
+                self.table = None
+            if self.table is None and len(ents) > 1 and all(
+                    x["key"] is None or x["key"][2] != _wt_cache["gen"] for x in ents.values()):
+                self._upload(w.device)
+        if self.table is not None and self.table_n == len(ents):
+            # refresh every registered tensor in one launch (they all went stale together: same optimizer step)
+            _C.call(self.multi, _p(self.table), self.table_n, self.total, _stream())
+            for x in ents.values():
+                t = x["ref"]()
+                x["key"] = _wt_key(t) if t is not None else None
+            e["key"] = key
+            return e["buf"]
+        self.single(w, e["buf"], _stream())
+        e["key"] = key
+        return e["buf"]
+
+
+def _wt_alloc(w):
+    k, c, kh, kw = w.shape
+    return torch.empty((c, kh, kw, k), device=w.device, dtype=torch.float32)
+
+
+def _wt_single(w, buf, st):
+    k, c, kh, kw = w.shape
+    _C.call("vspw_weight_transpose", _p(w), _p(buf), k, kh * kw, c, st)
+
+
+_wt_copies = _DerivedWeights(_wt_alloc, _wt_single, "vspw_weight_transpose_multi",
+                             lambda k, c, kh, kw: _C.query("vspw_weight_transpose_tiles", k, kh * kw, c))
+
+
+def _transposed_weight(w):
+    """wT for the data gradient of a conv with weight w ([K][KH][KW][C] memory), from the per-step cache."""
+    return _wt_copies.get(w)
+
+
+def _wu_alloc(w):
+    k, c, kh, kw = w.shape
+    return torch.empty((2, 16, k * c), device=w.device, dtype=torch.float32)
+
+
+def _wu_single(w, buf, st):
+    k, c, kh, kw = w.shape
+    _C.call("vspw_wino_weights", _p(w), _p(buf[0]), k, c, 0, st)
+    _C.call("vspw_wino_weights", _p(w), _p(buf[1]), k, c, 1, st)
+
+
+_wu_copies = _DerivedWeights(_wu_alloc, _wu_single, "vspw_wino_weights_multi",
+                             lambda k, c, kh, kw: _C.query("vspw_wino_weight_tiles", k, c))
+
+
+def _wino_weights(w, data_gradient):
+    """U [16][Cout][Cin] (forward) or U' [16][Cin][Cout] (data gradient) of a 3x3 weight, from the per-step cache."""
+    return _wu_copies.get(w)[1 if data_gradient else 0]
+
+
+def drop_weight_transpose_cache():
+    _wt_copies.clear()
+    _wu_copies.clear()
+
+
+def conv2d_backward_data(dy, w, d, addend=None, bn_front=None, aff=None):
+    """dx = conv_backward_input(dy, w) [+ addend, folded into the GEMM epilogue].
+    bn_front = (z, link): additionally apply the ReLU mask of the node that produced this conv's input z and leave the
+    two batch-norm-backward reductions of that node in link.partials (see BNLink); returns the masked gradient.
+    aff = (y, coef): `dy` is really g, the gradient w.r.t. the BatchNorm OUTPUT; the GEMM stages
+    coef[0]*g + coef[1]*y + coef[2] (BatchNorm's backward apply) as its operand (pointwise convs only)."""
+    k, c, kh, kw = w.shape
+    dx = empty_nhwc(d.n, d.c, d.h, d.w, dy.device)
+    if aff is None and addend is None and _wino_ok(d):
+        front = part = None
+        if bn_front is not None:
+            z, link = bn_front
+            front = (z, link.y, link.mean, link.invstd)
+            part = torch.empty((_C.query("vspw_wino_stat_partials", ctypes.byref(d)), 2, d.c), device=dy.device,
+                               dtype=torch.float32)
+        _wino_conv(d, dy, w, d.c, d.k, True, None, dx, front=front, part=part, what="dgrad")
+        if bn_front is not None:
+            link.partials, link.g = part, dx
+        return dx
+    wT = _transposed_weight(w)
+    if aff is not None:
+        y_, coef = aff
+        if addend is not None:
+            addend = to_nhwc(addend)
+        zz = link = part = None
+        if bn_front is not None:
+            zz, link = bn_front
+            tiles = _C.query("vspw_conv2d_bwd_data_bn_partials", ctypes.byref(d))
+            part = torch.empty((tiles, 2, d.c), device=dy.device, dtype=torch.float32)
+        with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "dgrad")):
+            _C.call("vspw_conv2d_bwd_data_aff", ctypes.byref(d), _p(dy), _p(y_), _p(coef), _p(wT), _p(addend), _p(zz),
+                    _p(link.y) if link else None, _p(link.mean) if link else None,
+                    _p(link.invstd) if link else None, _p(dx), _p(part), _stream())
+        if link is not None:
+            link.partials, link.g = part, dx
+        return dx
+    if addend is not None:
+        addend = to_nhwc(addend)
+        if tuple(addend.shape) != tuple(dx.shape):
+            raise RuntimeError("conv2d_backward_data: addend %s vs dx %s" % (tuple(addend.shape), tuple(dx.shape)))
+    if bn_front is not None:
+        z, link = bn_front
+        tiles = _C.query("vspw_conv2d_bwd_data_bn_partials", ctypes.byref(d))
+        part = torch.empty((tiles, 2, d.c), device=dy.device, dtype=torch.float32)
+        with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "dgrad")):
+            _C.call("vspw_conv2d_bwd_data_bn", ctypes.byref(d), _p(dy), _p(wT), _p(addend), _p(z), _p(link.y),
+                    _p(link.mean), _p(link.invstd), _p(dx), _p(part), _stream())
+        link.partials, link.g = part, dx
+        return dx
+    with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "dgrad")):
+        if addend is None:
+            _C.call("vspw_conv2d_bwd_data", ctypes.byref(d), _p(dy), _p(wT), _p(dx), _stream())
+        else:
+            _C.call("vspw_conv2d_bwd_data_acc", ctypes.byref(d), _p(dy), _p(wT), _p(addend), _p(dx), _stream())
+    return dx
+
+
+# Weight gradients are leaves of the backward pass: nothing downstream of a convolution's dW is needed before the
+# optimizer step (or the bucket all-reduce), while dX is on the critical path.  They are issued on a second HIP stream
+# (fork after dY is ready; joined by an autograd end-of-backward callback, and before any bucket all-reduce) so that
+# the split-K weight-gradient GEMM of layer i overlaps the BatchNorm-backward passes and the data-gradient GEMM of
+# layer i-1 and fills their launch tails; under a captured hipGraph the fork/join become graph edges (no host events).
+# Measured on the bench step: 116.1 -> 114.4 ms, bit-identical results.  VSPW_WGRAD_STREAM=0 disables it.
+_wgrad_side = {"enabled": os.environ.get("VSPW_WGRAD_STREAM", "1") == "1", "stream": None, "keep": [], "dirty": False}
+
+
+def set_wgrad_side_stream(enabled):
+    join_side_streams()
+    _wgrad_side["enabled"] = bool(enabled)
+
+
+def join_side_streams():
+    """Make the current stream wait for every weight-gradient GEMM issued on the side stream (call before anything
+    reads parameter gradients: optimizer step, gradient all-reduce, gradient inspection)."""
+    if _wgrad_side["dirty"]:
+        torch.cuda.current_stream().wait_stream(_wgrad_side["stream"])
+        _wgrad_side["keep"].clear()
+        _wgrad_side["dirty"] = False
+
+
+def _wino_wgrad(dy, x, d, dw, v=None):
+    """dW of a stride-1 3x3 convolution in the Winograd domain (see winograd.hip): 4/9 of the direct multiplications.
+    v: the input transform kept by the forward pass (recomputed from x when absent)."""
+    dev, st = dy.device, _stream()
+    T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
+    if v is None or tuple(v.shape) != (16, T, d.c):
+        v = torch.empty((16, T, d.c), device=dev, dtype=torch.float32)
+        _C.call("vspw_wino_input", ctypes.byref(d), _p(x), d.c, _p(v), st)
+    dm = torch.empty((16, T, d.k), device=dev, dtype=torch.float32)
+    _C.call("vspw_wino_dy", ctypes.byref(d), _p(dy), d.k, _p(dm), st)
+    du = torch.empty((16, d.k, d.c), device=dev, dtype=torch.float32)
+    nbytes = _C.query("vspw_bmm_tn_workspace", 16, T, d.k, d.c)
+    ws = _ws(nbytes, dev) if nbytes else None
+    with _Timed("igemm_tn_kernel", 2.0 * 16 * T * d.k * d.c, _conv_tag(d, "wgrad-wino"), _conv_flops(d)):
+        _C.call("vspw_bmm_tn", _p(dm), _p(v), _p(du), 16, T, d.k, d.c, _p(ws), nbytes, st)
+    _C.call("vspw_wino_dw", _p(du), _p(dw), d.k, d.c, st)
+    _wino["launches"] += 1
+
+
+def _wgrad_launch(dy, x, d, aff=None, wino_v=None):
+    dw = torch.empty((d.k, d.kh, d.kw, d.c), device=dy.device, dtype=torch.float32).permute(0, 3, 1, 2)
+    if aff is None and _wino["wgrad"] and _wino_ok(d):
+        _wino_wgrad(dy, x, d, dw, wino_v)
+        return dw, None
+    nbytes = _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d))
+    ws = _ws(nbytes, dy.device) if nbytes else None
+    with _Timed("igemm_tn_kernel", _conv_flops(d), _conv_tag(d, "wgrad")):
+        if aff is None:
+            _C.call("vspw_conv2d_bwd_weight", ctypes.byref(d), _p(dy), _p(x), _p(dw), _p(ws), nbytes, _stream())
+        else:
+            _C.call("vspw_conv2d_bwd_weight_aff", ctypes.byref(d), _p(dy), _p(aff[0]), _p(aff[1]), _p(x), _p(dw), _p(ws),
+                    nbytes, _stream())
+    return dw, ws
+
+
+def conv2d_backward_weight(dy, x, d, aff=None, wino_v=None):
+    """aff = (y, coef): see conv2d_backward_data.  wino_v: see _wino_wgrad."""
+    if not _wgrad_side["enabled"] or _ktimer["on"]:
+        return _wgrad_launch(dy, x, d, aff, wino_v)[0]
+    main = torch.cuda.current_stream()
+    side = _wgrad_side["stream"]
+    if side is None:
+        side = _wgrad_side["stream"] = torch.cuda.Stream(device=dy.device)
+    side.wait_stream(main)  # fork: dY (and X) are complete on the main stream
+    with torch.cuda.stream(side):
+        dw, ws = _wgrad_launch(dy, x, d, aff, wino_v)
+    # dY / X / the workspace were allocated on the main stream's pool: keep them alive until the join so that the
+    # allocator cannot hand their memory to a later main-stream kernel while the side-stream GEMM still reads it
+    # (dW itself must NOT be referenced here: with a second owner autograd's AccumulateGrad would clone it - a copy on
+    # the main stream that races with the side-stream GEMM - instead of adopting the tensor as p.grad)
+    if torch.cuda.is_current_stream_capturing():
+        _wgrad_side["keep"].append((dy, x, ws, aff, wino_v))  # graph-private pool: nothing is recycled before the join anyway
+    else:
+        # eager: tell the caching allocator that the side stream uses these blocks - each is recycled as soon as ITS
+        # GEMM has finished, so saved activations and dY tensors are released progressively during backward (a list
+        # held until the join kept the sum of all dY tensors + split-K workspaces of a backward pass alive)
+        for t in (dy, x, ws, wino_v) + (tuple(aff) if aff is not None else ()):
+            if t is not None:
+                t.record_stream(side)
+    if not _wgrad_side["dirty"]:
+        _wgrad_side["dirty"] = True
+        try:  # join when this backward pass ends, so that p.grad is safe to read on the main stream afterwards
+            torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+        except RuntimeError:
+            pass  # not inside a backward pass (direct call from a test): the caller joins
+    return dw
+
+
+def colsum(a2d_rows, c, a, b=None):
+    nbytes = _C.query("vspw_colsum_workspace", a2d_rows, c)
+    ws = _ws(nbytes, a.device)
+    out = torch.empty(c, device=a.device, dtype=torch.float32)
+    _C.call("vspw_colsum_prod", _p(a), _p(b), _p(out), a2d_rows, c, _p(ws), nbytes, _stream())
+    return out
+
+
+class Conv2dFn(torch.autograd.Function):
+    """nn.Conv2d forward/backward on the implicit-GEMM MFMA kernels (csrc/conv_igemm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, dil):
+        x = to_nhwc(x)
+        y, _, d = conv2d_forward(x, w, bias, stride, pad, dil, wgrad=ctx.needs_input_grad[1])
+        ctx.d = d
+        ctx.has_bias = bias is not None
+        ctx.wino_v = getattr(y, "_vspw_wino_v", None)
+        y._vspw_wino_v = None
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        d = ctx.d
+        dy = to_nhwc(dy)
+        if not is_nhwc(w):
+            w = w.contiguous(memory_format=torch.channels_last)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_backward_data(dy, w, d)
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_backward_weight(dy, x, d, wino_v=ctx.wino_v)
+        ctx.wino_v = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(d.n * d.oh * d.ow, d.k, dy)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0, dil=1):
+    return Conv2dFn.apply(x, w, bias, stride, pad, dil)

@@ -32,10 +32,11 @@ struct WinoRowsP {
     float* tp;       // [4][2][tpad][rows]
     int T, tpad, c, rows;
     int nb, h, w, lds, tpi, d, th, tw;  // FUSED only: source geometry, tiles per image, dilation, tiles per sub-grid
+    int dbg;  // experiments (vspw_wino_rows_config(tile + 100 * dbg)): 1 = no stores, 2 = no K loop
 };
 
 template <int WGM, int WM, int WN, int FUSED, int MINB>
-__global__ __launch_bounds__(256, MINB) void wino_rows_kernel(WinoRowsP p) {
+__global__ __launch_bounds__(256, MINB) void igemm_nt_wrows_kernel(WinoRowsP p) {
     constexpr int WGN = 4 / WGM;
     constexpr int TM = 32 * WM * WGM, TN = 32 * WN * WGN;
     constexpr int RA = TM / 32, RB = TN / 32;
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256, MINB) void wino_rows_kernel(WinoRowsP p) {
     float* As = smem;
     float* Bs = smem + TM * WR_LDA;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (WGM == 2) ? (wave >> 1) : 0, wn = (WGM == 2) ? (wave & 1) : wave;
     const int l31 = lane & 31, lh = lane >> 5;
     __builtin_amdgcn_s_setprio(2);
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256, MINB) void wino_rows_kernel(WinoRowsP p) {
         for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) P0[i][j][r] = P1[i][j][r] = 0.f;
-    const int nkb = p.c / WR_BK;
+    const int nkb = (p.dbg & 2) ? 0 : p.c / WR_BK;
     auto gemm = [&](f32x16 (&acc)[WM][WN]) {  // one transform position: Cin / 32 K-tiles of the shared pipeline
         for (int kt = 0; kt < nkb; ++kt) {
             store_tile();
@@ -219,22 +220,30 @@ __global__ __launch_bounds__(256, MINB) void wino_rows_kernel(WinoRowsP p) {
         }
     };
     // stores: every tile is interior (tpad rows, rows % TN == 0): 32x32 blocks through a wave-private LDS scratch so
-    // that a lane stores 16 bytes (4 consecutive channels) - the operand tiles are dead behind the loop's last barrier
-    float* scr = smem + wave * (32 * WR_LDA);
+    // that a lane stores 16 bytes (4 consecutive channels).  Raw buffer stores: the wave's block origin is the scalar
+    // base, one per-lane offset register serves every block.
+    float* scr = smem + wave * (32 * WR_LDA);  // (the operand tiles are dead behind the loop's last barrier)
     const int erow = lane >> 3, ec4 = (lane & 7) * 4;
     const size_t plane_t = (size_t)p.tpad * p.rows;
-    auto store_plane = [&](f32x16 (&acc)[WM][WN], float* base) {
+    const unsigned st_voff = (unsigned)(erow * p.rows + ec4) * 4u;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    auto store_plane = [&](f32x16 (&acc)[WM][WN], int j01) {
+        float* org = p.tp + (size_t)(ar * 2 + j01) * plane_t + (size_t)(m0 + wm * 32 * WM) * p.rows + n0 + wn * 32 * WN;
+        const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(org, 0, 0x7ffffffc, 0x00020000);
 #pragma unroll
         for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int i = 0; i < WM; ++i) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * WR_LDA + l31] = acc[i][j][r];
-                float* out = base + (size_t)(m0 + wm * 32 * WM + i * 32 + erow) * p.rows + n0 + wn * 32 * WN + j * 32 + ec4;
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq)
-                    *reinterpret_cast<f32x4*>(out + (size_t)(rq * 8) * p.rows) =
-                        *reinterpret_cast<const f32x4*>(&scr[(rq * 8 + erow) * WR_LDA + ec4]);
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        __builtin_bit_cast(u32x4, *reinterpret_cast<const f32x4*>(&scr[(rq * 8 + erow) * WR_LDA + ec4])),
+                        rs_o, st_voff, (unsigned)(((i * 32 + rq * 8) * p.rows + j * 32) * 4), 0);
+                // one block at a time: unfenced, the scheduler reads every block back from the scratch before the first
+                // store (16 registers per block) and spills the accumulators
+                __builtin_amdgcn_sched_barrier(0);
             }
     };
     __builtin_amdgcn_s_setprio(0);
@@ -252,16 +261,30 @@ __global__ __launch_bounds__(256, MINB) void wino_rows_kernel(WinoRowsP p) {
     gemm(P0);  // + M[a][0]
     gemm(P1);  // - M[a][3]
     __builtin_amdgcn_s_setprio(2);
-    // (tried: storing P[a][0] before the fourth GEMM so that its stores drain behind it - the longer live ranges spill
-    // 88 registers of the 96-row tile at three workgroups per CU: 157 -> 205 us)
-    store_plane(P0, p.tp + (size_t)(ar * 2 + 0) * plane_t);
-    store_plane(P1, p.tp + (size_t)(ar * 2 + 1) * plane_t);
+    // (tried twice: storing P[a][0] - final at this point - before the fourth GEMM, so that its stores drain behind the
+    // MFMAs instead of at the end of a one-round launch where every workgroup stores at once (15 of 169 us,
+    // tools/diag/wino_rows_probe.py "no stores"): with plain and with raw-buffer stores the 96-row tile then spills
+    // 88-140 registers at three workgroups per CU (157 -> 205 us))
+    if (p.dbg & 1) {  // keep the accumulators alive through a never-true store
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += P0[i][j][r] + P1[i][j][r];
+        if (t == 123.456f) p.tp[tid] = t;
+        return;
+    }
+    store_plane(P0, 0);
+    store_plane(P1, 1);
 }
 
 // Tile choice (code as in conv_igemm.hip's nt_pick_tile): 64 x 128 (12), 96 x 128 (31) at three workgroups per CU when
 // V is read from memory, two with the fused operand (its four staged pixels per row need the registers); 128 x 128 (22)
 // at two.  vspw_wino_rows_config(code) / VSPW_WROWS_TILE force one (experiments); 0 = automatic.
 static int wr_forced = -1;
+static int wr_dbg = 0;
 static int wr_tile_rows(int cfg) { return cfg == 22 ? 128 : (cfg == 31 ? 96 : 64); }
 static int wr_tile(long long T, int rows, bool fused = false) {
     if (wr_forced < 0) wr_forced = getenv("VSPW_WROWS_TILE") ? atoi(getenv("VSPW_WROWS_TILE")) : 0;
@@ -284,8 +307,11 @@ static int wr_tile(long long T, int rows, bool fused = false) {
 }
 
 extern "C" int vspw_wino_rows_config(int tile) {
-    if (tile != 0 && tile != 12 && tile != 31 && tile != 22) return VSPW_EINVAL;
+    const int dbg = tile / 100;
+    tile %= 100;
+    if ((tile != 0 && tile != 12 && tile != 31 && tile != 22) || dbg < 0 || dbg > 3) return VSPW_EINVAL;
     wr_forced = tile;
+    wr_dbg = dbg;
     return VSPW_OK;
 }
 
@@ -304,7 +330,7 @@ static bool wr_geom(const vspw_conv_desc* d, int channels, int rows, WinoRowsP& 
     if (4 * T * channels * 4 >= 0x7fffffffLL || 4LL * rows * channels * 4 >= 0x7fffffffLL) return false;
     const long long span = (128 / tpi + 2) * (long long)d->h * d->w * channels * 4;
     if (span >= (1LL << 30) || tpad * rows / 64 * 4 > 0x3fffffffLL) return false;
-    p.T = (int)T; p.tpad = (int)tpad; p.c = channels; p.rows = rows;
+    p.T = (int)T; p.tpad = (int)tpad; p.c = channels; p.rows = rows; p.dbg = wr_dbg;
     p.nb = d->n; p.h = d->h; p.w = d->w; p.lds = channels; p.tpi = (int)tpi; p.d = dl; p.th = th; p.tw = tw;
     return true;
 }
@@ -338,11 +364,12 @@ static int wr_launch(WinoRowsP& p, hipStream_t st) {
         if constexpr (FUSED)
             return VSPW_EINVAL;  // (the fused operand's staging registers do not fit next to 128 accumulators)
         else
-            hipLaunchKernelGGL((wino_rows_kernel<2, 2, 2, 0, 2>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    } else if (cfg == 31)
-        hipLaunchKernelGGL((wino_rows_kernel<1, 3, 1, FUSED, FUSED ? 2 : 3>), dim3((unsigned)grid), dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL((wino_rows_kernel<2, 1, 2, FUSED, FUSED ? 2 : 3>), dim3((unsigned)grid), dim3(256), 0, st, p);
+            hipLaunchKernelGGL((igemm_nt_wrows_kernel<2, 2, 2, 0, 2>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    } else if (cfg == 31) {
+        hipLaunchKernelGGL((igemm_nt_wrows_kernel<1, 3, 1, FUSED, FUSED ? 2 : 3>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((igemm_nt_wrows_kernel<2, 1, 2, FUSED, FUSED ? 2 : 3>), dim3((unsigned)grid), dim3(256), 0, st, p);
+    }
     return vspw_launch_status();
 }
 

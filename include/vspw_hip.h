@@ -181,7 +181,8 @@ long long vspw_wino_rows_tpad(const vspw_conv_desc* d, int channels, int rows, i
  * reduction short enough for the halved M traffic to matter): the dispatch rule callers use. */
 int vspw_wino_rows_prefer(const vspw_conv_desc* d, int channels, int rows, int fused);
 /* Tuning knob (experiments): force the GEMM tile of the row-fused form - 12 (64x128), 31 (96x128), 22 (128x128); 0 =
- * automatic.  Changes vspw_wino_rows_tpad: set it before sizing buffers. */
+ * automatic.  Changes vspw_wino_rows_tpad: set it before sizing buffers.  (+100: timing build without the stores,
+ * +200: without the K loop - results are then meaningless.) */
 int vspw_wino_rows_config(int tile);
 int vspw_wino_gemm_rows(const vspw_conv_desc* d, const float* v, int channels, const float* u, int rows, float* tp,
                         void* stream);

@@ -130,6 +130,14 @@ def main():
                 e = (ys[0] - y_ref).abs().max().item()
                 print("%-26s %-22s %8s %8.1f %8.1f %8.1f  %.2e" % ("", "rows tile %d, fused V" % tile, "-", tg3, to2,
                                                                   tg3 + to2, e))
+        for tile, what in ((131, "tile 31, no stores"), (231, "tile 31, no K loop")):  # where the launch's time goes
+            _C.call("vspw_wino_rows_config", tile)
+            tpad = int(_C.query("vspw_wino_rows_tpad", ctypes.byref(d), c, k, 0))
+            if tpad:
+                tps = [torch.empty(8, tpad, k, device=dev) for _ in range(SETS)]
+                t = timeit(lambda i: _C.call("vspw_wino_gemm_rows", ctypes.byref(d), _p(vs[i]), c, _p(u), k, _p(tps[i]), st),
+                           iters)
+                print("%-26s %-22s %8s %8.1f" % ("", what, "", t))
         _C.call("vspw_wino_rows_config", 0)
 
 

@@ -23,7 +23,7 @@ def load(path):
 
 
 def group(name):
-    if name.startswith("igemm_nt"):
+    if name.startswith("igemm_nt"):  # (incl. igemm_nt_wrows_kernel, the row-fused Winograd GEMM)
         return "igemm_nt_kernel"
     if name.startswith("igemm_tn"):
         return "igemm_tn_kernel"

@@ -186,6 +186,37 @@ class BaseDataset_clip(_TrainBase):
         return self._finish(video, [imglist[i] for i in range(imgid, imgid + self.clipnum)], flip_flag, scale)
 
 
+class BaseDataset(_TrainBase):
+    """dataset2.py:494-650: the PER-FRAME dataset (train.py's feed for the per-frame PSPNet / OCRNet heads): every
+    int(15 / trainfps)-th frame of every video of the split (val: every 15th); train: flip, multi-scale resize, pad to
+    the crop size, random crop - one frame, same draw order as the clip datasets; val: the whole frame."""
+
+    def __init__(self, args, split="train"):
+        clip_num = getattr(args, "clip_num", 1)
+        if not hasattr(args, "clip_num"):
+            args.clip_num = clip_num
+        super().__init__(args, split)
+        if getattr(args, "train_filter", False):
+            self.cropsize = (480, 720)
+        if self.split == "val":
+            self.trainfps = 1
+        num = int(15. / self.trainfps)
+        self.imglist = [(video, name) for video in self.videolists
+                        for k, name in enumerate(self.imgdic[video]) if k % num == 0]
+
+    def __len__(self):
+        return len(self.imglist)
+
+    def __getitem__(self, idx):
+        video, name = self.imglist[idx]
+        flip_flag, scale = 0, 1.
+        if self.split == "train":
+            flip_flag = np.random.choice([0, 1])
+            if getattr(self.args, "multi_scale", False):
+                scale = np.random.choice(self.scale)
+        return self._finish(video, [name], flip_flag, scale)
+
+
 class _TestBase(_VSPWBase):
     def __init__(self, dataroot, video, args, is_train=False):
         self.dataroot = dataroot

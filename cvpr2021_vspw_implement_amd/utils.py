@@ -80,7 +80,60 @@ def get_common(gt_list, pred_list, clip_num, h, w):
     return accs
 
 
+# ------------------------------------------------------------------------------------------- per-image metrics
+def unique(ar, return_index=False, return_inverse=False, return_counts=False):
+    """utils.py:170-210: sorted distinct values of the flattened array (numpy.unique's contract)."""
+    return np.unique(np.asanyarray(ar).ravel(), return_index=return_index, return_inverse=return_inverse,
+                     return_counts=return_counts)
+
+
+def colorEncode(labelmap, colors, mode="RGB"):
+    """utils.py:213-227: label map [h,w] -> uint8 colour image [h,w,3] through the table `colors` [n,3]; negative
+    labels stay black; mode 'BGR' reverses the channel order."""
+    lab = np.asarray(labelmap).astype("int")
+    table = np.asarray(colors).astype(np.uint8)
+    out = np.zeros(lab.shape + (3,), dtype=np.uint8)
+    ok = lab >= 0
+    out[ok] = table[lab[ok]]
+    return out[:, :, ::-1] if mode == "BGR" else out
+
+
+def accuracy(preds, label):
+    """utils.py:230-235: (pixel accuracy over label >= 0, number of such pixels)."""
+    valid = label >= 0
+    hit = (valid * (preds == label)).sum()
+    n = valid.sum()
+    return float(hit) / (n + 1e-10), n
+
+
+def intersectionAndUnion(imPred, imLab, numClass):
+    """utils.py:238-258: per-class intersection and union areas; label -1 (unlabeled) pixels count for nothing."""
+    pred = np.asarray(imPred).copy() + 1
+    lab = np.asarray(imLab).copy() + 1
+    pred = pred * (lab > 0)
+    inter = pred * (pred == lab)
+    edges = dict(bins=numClass, range=(1, numClass))
+    area_i = np.histogram(inter, **edges)[0]
+    area_p = np.histogram(pred, **edges)[0]
+    area_l = np.histogram(lab, **edges)[0]
+    return area_i, area_p + area_l - area_i
+
+
+def find_recursive(root_dir, ext=".jpg"):
+    """utils.py:125-132: every file under root_dir whose name ends in ext, hidden files skipped."""
+    import os
+
+    found = []
+    for root, _dirs, names in os.walk(root_dir):
+        found.extend(os.path.join(root, n) for n in names if n.endswith(ext) and not n.startswith("."))
+    return found
+
+
 # ------------------------------------------------------------------------------------------- driver conveniences
+class NotSupportedCliException(ValueError):
+    """utils.py:261 (a ValueError here too: callers that caught that keep working)."""
+
+
 def parse_devices(input_devices):
     """utils.py:282-302: '0-3' / '0,1' / 'gpu0-gpu2' -> ['gpu0', 'gpu1', ...] without duplicates."""
     import re
@@ -94,7 +147,7 @@ def parse_devices(input_devices):
         else:
             m = re.match(r"^(?:gpu)?(\d+)-(?:gpu)?(\d+)$", d)
             if not m:
-                raise ValueError('Can not recognize device: "{}"'.format(d))
+                raise NotSupportedCliException('Can not recognize device: "{}"'.format(d))
             a, b = int(m.group(1)), int(m.group(2))
             if a > b:
                 a, b = b, a

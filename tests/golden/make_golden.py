@@ -523,6 +523,88 @@ def case_datasets(tag="vspw_datasets"):
     print(tag, len(res), "arrays")
 
 
+def case_frame_dataset(tag="vspw_dataset_frame"):
+    """The reference's PER-FRAME dataset (dataset2.py:494-650, BaseDataset: what train.py feeds the per-frame PSPNet /
+    OCRNet of cfg 1-2) on the tiny VSPW tree: the frame list at `trainfps`, the seeded flip / scale / crop draws of the
+    train split and the un-augmented val split."""
+    import random
+    import tempfile
+
+    import dataset2 as D
+    from oracle.det_data import make_tiny_vspw
+
+    root = tempfile.mkdtemp(prefix="vspw_tiny_")
+    make_tiny_vspw(root)
+    res = {}
+    for ms in (False, True):
+        a = args_ns(cropsize=40, dataroot=root, trainfps=5, multi_scale=ms, lesslabel=False, train_filter=False)
+        ds = D.BaseDataset(a, "train")
+        res["train:len"] = np.int64(len(ds))
+        res["train:list"] = np.array(["%s/%s" % vi for vi in ds.imglist])
+        for seed in (0, 1, 2, 3, 4, 5):
+            np.random.seed(500 + seed)
+            random.seed(600 + seed)
+            img, seg = ds[(7 * seed + 1) % len(ds)]
+            res["train:ms%d:seed%d:img" % (ms, seed)] = img.numpy()
+            res["train:ms%d:seed%d:seg" % (ms, seed)] = seg.numpy()
+    a = args_ns(cropsize=40, dataroot=root, trainfps=5, multi_scale=True, lesslabel=False, train_filter=False)
+    dv = D.BaseDataset(a, "val")
+    res["val:len"] = np.int64(len(dv))
+    res["val:list"] = np.array(["%s/%s" % vi for vi in dv.imglist])
+    for index in (0, len(dv) - 1):
+        img, seg = dv[index]
+        res["val:%d:img" % index] = img.numpy()
+        res["val:%d:seg" % index] = seg.numpy()
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, len(res), "arrays; train frames", int(res["train:len"]), "val frames", int(res["val:len"]))
+
+
+def case_helpers(tag="helpers_reference"):
+    """Host-side helpers the reference's test driver imports (test_clip2.py:16-18): utils.colorEncode / accuracy /
+    intersectionAndUnion / unique / find_recursive and lib.utils.as_numpy, captured on seeded inputs."""
+    import tempfile
+
+    import collections
+    import collections.abc
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("ref_utils_py", os.path.join(REF, "utils.py"))  # (RAFT_core/utils
+    U = importlib.util.module_from_spec(spec)                                                      # shadows the name)
+    spec.loader.exec_module(U)
+    for n in ("Sequence", "Mapping"):  # lib/utils/th.py predates their move to collections.abc
+        if not hasattr(collections, n):
+            setattr(collections, n, getattr(collections.abc, n))
+    from lib.utils import as_numpy
+
+    rs = np.random.RandomState(11)
+    res = {}
+    lab = rs.randint(-1, 9, size=(13, 17))
+    colors = rs.randint(0, 256, size=(9, 3)).astype(np.uint8)
+    res["labelmap"], res["colors"] = lab, colors
+    res["colorEncode:RGB"] = U.colorEncode(lab.copy(), colors)
+    res["colorEncode:BGR"] = np.ascontiguousarray(U.colorEncode(lab.copy(), colors, mode="BGR"))
+    pred = rs.randint(0, 9, size=(13, 17))
+    res["pred"] = pred
+    acc, n = U.accuracy(pred, lab)
+    res["accuracy"] = np.array([acc, float(n)])
+    inter, union = U.intersectionAndUnion(pred, lab, 9)
+    res["intersection"], res["union"] = inter, union
+    u, idx, inv, cnt = U.unique(lab.copy(), True, True, True)
+    res["unique"], res["unique_index"], res["unique_inverse"], res["unique_counts"] = u, idx, inv, cnt
+    root = tempfile.mkdtemp(prefix="find_")
+    for rel in ("a/x.jpg", "a/.hidden.jpg", "a/b/y.jpg", "a/b/z.png", "c/w.jpg"):
+        os.makedirs(os.path.join(root, os.path.dirname(rel)), exist_ok=True)
+        open(os.path.join(root, rel), "w").close()
+    res["find_recursive:jpg"] = np.array(sorted(os.path.relpath(f, root) for f in U.find_recursive(root)))
+    res["find_recursive:png"] = np.array(sorted(os.path.relpath(f, root) for f in U.find_recursive(root, ext=".png")))
+    nested = as_numpy({"a": [torch.arange(3), (torch.ones(2, 2), 5)], "b": torch.tensor(2.5)})
+    res["as_numpy:a0"], res["as_numpy:a1_0"], res["as_numpy:a1_1"], res["as_numpy:b"] = (
+        nested["a"][0], nested["a"][1][0], nested["a"][1][1], nested["b"])
+    res["as_numpy:types"] = np.array([type(nested).__name__, type(nested["a"]).__name__, type(nested["a"][1]).__name__])
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, len(res), "arrays")
+
+
 def case_ops(M, tag="ops_reference"):
     """Op-level vectors straight from the reference's own helper functions."""
     import models.netwarp as ref_nw
@@ -938,6 +1020,10 @@ def main():
         case_raft()
     if want("vspw_datasets"):
         case_datasets()
+    if want("vspw_dataset_frame"):
+        case_frame_dataset()
+    if want("helpers_reference"):
+        case_helpers()
     if want("r50_clip_psp_fixbn"):
         case_fixbn(M, "clip_psp", "resnet50dilated", "r50_clip_psp_fixbn")
     if want("r50_clip_ocr_fixbn"):

@@ -64,6 +64,37 @@ def test_train_datasets_draw_and_transform_like_the_reference(tree):
         _check(fx, "clip:seed%d" % seed, ds[seed % len(ds)])
 
 
+def test_per_frame_dataset_like_the_reference(tree):
+    """dataset2.BaseDataset (train.py's per-frame feed, cfg 1-2): frame list at trainfps, seeded flip / scale / crop of
+    the train split, whole frames of the val split - against the reference's own class on the same tree."""
+    import cvpr2021_vspw_implement_amd.dataset2 as D
+
+    fx = golden("vspw_dataset_frame")
+    seen = set()
+    for ms in (False, True):
+        a = args_ns(cropsize=40, dataroot=tree, trainfps=5, multi_scale=ms, lesslabel=False, train_filter=False)
+        ds = D.BaseDataset(a, "train")
+        assert len(ds) == int(fx["train:len"])
+        assert ["%s/%s" % vi for vi in ds.imglist] == [str(x) for x in fx["train:list"]]
+        for seed in (0, 1, 2, 3, 4, 5):
+            np.random.seed(500 + seed)
+            random.seed(600 + seed)
+            s = ds[(7 * seed + 1) % len(ds)]
+            seen.add((s.spec.flip, (s.spec.new_h, s.spec.new_w) != s.frames[0].shape[:2]))
+            imgs, labs = _apply_oracle(s)
+            assert np.array_equal(imgs[0], fx["train:ms%d:seed%d:img" % (ms, seed)]), (ms, seed)
+            assert np.array_equal(labs[0], fx["train:ms%d:seed%d:seg" % (ms, seed)]), (ms, seed)
+    assert {f for f, _ in seen} == {0, 1} and {r for _, r in seen} == {False, True}
+    a = args_ns(cropsize=40, dataroot=tree, trainfps=5, multi_scale=True, lesslabel=False, train_filter=False)
+    dv = D.BaseDataset(a, "val")
+    assert len(dv) == int(fx["val:len"])
+    assert ["%s/%s" % vi for vi in dv.imglist] == [str(x) for x in fx["val:list"]]
+    for index in (0, len(dv) - 1):
+        imgs, labs = _apply_oracle(dv[index])
+        assert np.array_equal(imgs[0], fx["val:%d:img" % index])
+        assert np.array_equal(labs[0], fx["val:%d:seg" % index])
+
+
 def test_test_datasets_like_the_reference(tree):
     import cvpr2021_vspw_implement_amd.dataset2 as D
 

@@ -60,6 +60,34 @@ def test_train_batches_bit_exact(dev, tree):
         _check(fx, "clip:seed%d" % seed, imgs, labs)
 
 
+def test_per_frame_batches_bit_exact(dev, tree):
+    """dataset2.BaseDataset (the per-frame feed of train.py, cfg 1-2) through the device pipeline: a batch of six
+    differently flipped / scaled / cropped frames and the un-augmented val frames equal the reference's tensors."""
+    import cvpr2021_vspw_implement_amd.dataset2 as D
+
+    fx = golden("vspw_dataset_frame")
+    tf = D.DeviceTransform(dev)
+    for ms in (False, True):
+        a = args_ns(cropsize=40, dataroot=tree, trainfps=5, multi_scale=ms, lesslabel=False, train_filter=False)
+        ds = D.BaseDataset(a, "train")
+        samples = []
+        for seed in (0, 1, 2, 3, 4, 5):
+            np.random.seed(500 + seed)
+            random.seed(600 + seed)
+            samples.append(ds[(7 * seed + 1) % len(ds)])
+        imgs, labs = tf(D.collate_raw(samples))
+        assert len(imgs) == 1 and imgs[0].shape == (6, 3, 40, 40)
+        for b in range(6):
+            assert np.array_equal(imgs[0][b].cpu().numpy(), fx["train:ms%d:seed%d:img" % (ms, b)]), (ms, b)
+            assert np.array_equal(labs[0][b].cpu().numpy(), fx["train:ms%d:seed%d:seg" % (ms, b)]), (ms, b)
+    a = args_ns(cropsize=40, dataroot=tree, trainfps=5, multi_scale=True, lesslabel=False, train_filter=False)
+    dv = D.BaseDataset(a, "val")
+    for index in (0, len(dv) - 1):
+        imgs, labs = tf([dv[index]])
+        assert np.array_equal(imgs[0][0].cpu().numpy(), fx["val:%d:img" % index])
+        assert np.array_equal(labs[0][0].cpu().numpy(), fx["val:%d:seg" % index])
+
+
 def test_test_frames_bit_exact(dev, tree):
     import cvpr2021_vspw_implement_amd.dataset2 as D
 

@@ -242,6 +242,27 @@ class _TestBase(_VSPWBase):
         return RawSample(frames, masks, FrameSpec(h, w), imagenames)
 
 
+class TestDataset(_VSPWBase):
+    """dataset2.py:34-141: the PER-FRAME test dataset (test.py's feed): every frame of one video, no augmentation;
+    `use_720p` resizes frame and mask to 1080 x 720 (PIL bilinear / nearest) first.  names = the mask's file name."""
+
+    def __init__(self, dataroot, video, args):
+        self.dataroot = dataroot
+        self.video = video
+        self.args = args
+        self.imglist = sorted(os.listdir(os.path.join(self.dataroot, "data", video, "origin")))
+
+    def __len__(self):
+        return len(self.imglist)
+
+    def __getitem__(self, idx):
+        name = self.imglist[idx]
+        img, seg = self._load(self.video, name)
+        h, w = img.shape[:2]
+        new_hw = (720, 1080) if getattr(self.args, "use_720p", False) else None
+        return RawSample([img], [seg], FrameSpec(h, w, 0, new_hw), name.split(".")[0] + ".png")
+
+
 class TestDataset_longclip(_TestBase):
     """dataset2.py:344-490: frame `index` plus the frames at +dilation2 offsets (mirrored backwards at the end)."""
 
@@ -408,7 +429,9 @@ class DeviceTransform(object):
         _C.call("vspw_gather_u8", seg.data_ptr(), seg2.data_ptr(), xt.data_ptr(), yt.data_ptr(), w, nh, nw, spec.flip, st)
         return cur, seg2
 
-    def __call__(self, samples):
+    def __call__(self, samples, frames_as_batch=False):
+        """frames_as_batch: ONE tensor pair holding all T x B frames, frame-major - what train.py:41-44 builds with
+        torch.cat(clip_imgs, dim=0) when the clip dataset feeds a per-frame model - written in place, no concatenation."""
         B = len(samples)
         T = len(samples[0].frames)
         s0 = samples[0].spec
@@ -417,8 +440,14 @@ class DeviceTransform(object):
             if (s.spec.out_h, s.spec.out_w) != (oh, ow) or len(s.frames) != T:
                 raise ValueError("samples of one batch must produce frames of one size (use a crop, or batch size 1)")
         st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        imgs = [torch.empty((B, oh, ow, 3), dtype=torch.float32, device=self.device) for _ in range(T)]
-        labs = [torch.empty((B, 1, oh, ow), dtype=torch.float32, device=self.device) for _ in range(T)]
+        if frames_as_batch:
+            allimg = torch.empty((T * B, oh, ow, 3), dtype=torch.float32, device=self.device)
+            alllab = torch.empty((T * B, 1, oh, ow), dtype=torch.float32, device=self.device)
+            imgs = [allimg[t * B:(t + 1) * B] for t in range(T)]
+            labs = [alllab[t * B:(t + 1) * B] for t in range(T)]
+        else:
+            imgs = [torch.empty((B, oh, ow, 3), dtype=torch.float32, device=self.device) for _ in range(T)]
+            labs = [torch.empty((B, 1, oh, ow), dtype=torch.float32, device=self.device) for _ in range(T)]
         for b, s in enumerate(samples):
             sp = s.spec
             for t in range(T):
@@ -429,4 +458,6 @@ class DeviceTransform(object):
                 _C.call("vspw_frame_transform", img.data_ptr(), seg.data_ptr(), sp.new_h, sp.new_w, flip, sp.pad_h,
                         sp.pad_w, sp.crop_y, sp.crop_x, oh, ow, self._mean, self._std, imgs[t][b].data_ptr(),
                         labs[t][b].data_ptr(), st)
+        if frames_as_batch:
+            return [allimg.permute(0, 3, 1, 2)], [alllab]
         return [i.permute(0, 3, 1, 2) for i in imgs], labs

@@ -555,6 +555,21 @@ def case_frame_dataset(tag="vspw_dataset_frame"):
         img, seg = dv[index]
         res["val:%d:img" % index] = img.numpy()
         res["val:%d:seg" % index] = seg.numpy()
+    # per-frame TEST dataset (dataset2.py:34-141, test.py's feed): every frame of one video, optional 720p resize
+    a = args_ns(lesslabel=False, use_720p=False)
+    ts = D.TestDataset(root, "v_b", a)
+    res["test:len"] = np.int64(len(ts))
+    for index in (0, len(ts) - 1):
+        img, gt, name = ts[index]
+        res["test:%d:img" % index], res["test:%d:seg" % index] = img.numpy(), gt.numpy()
+        res["test:%d:name" % index] = np.array(name)
+    a = args_ns(lesslabel=False, use_720p=True)
+    img, gt, name = D.TestDataset(root, "v_b", a)[3]
+    res["test720:3:shape"] = np.array(img.shape)
+    res["test720:3:img_sub"] = img.numpy()[:, ::8, ::8].copy()   # (the full 3 x 720 x 1080 frame is 9 MB)
+    res["test720:3:seg_sub"] = gt.numpy()[:, ::8, ::8].copy()
+    res["test720:3:img_sum"] = np.float64(img.double().sum().item())
+    res["test720:3:seg_sum"] = np.float64(gt.double().sum().item())
     np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
     print(tag, len(res), "arrays; train frames", int(res["train:len"]), "val frames", int(res["val:len"]))
 
@@ -800,6 +815,55 @@ def _parser_defaults(path):
     return got
 
 
+def case_frame_drivers(M, tag="frame_drivers_reference"):
+    """Host-side definitions of the PER-FRAME drivers (train.py / test.py: the entry points of cfg 1-2,
+    scripts/run_psp.sh) captured from the reference: argparse flags and defaults, group_weight's decay / no-decay
+    partition (train.py:191-211), the two SGD optimizers (:214-226) and the poly schedule (:229-238)."""
+    import_reference_drivers()
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import train as ref_train  # noqa
+    finally:
+        os.chdir(cwd)
+    res = {}
+    for drv in ("train.py", "test.py"):
+        d = _parser_defaults(drv)
+        keys = sorted(d)
+        res["argparse:%s:dest" % drv] = np.array(keys)
+        res["argparse:%s:default" % drv] = np.array([d[k][0] for k in keys])
+        res["argparse:%s:type" % drv] = np.array([d[k][1] for k in keys])
+        res["argparse:%s:kind" % drv] = np.array([d[k][3] for k in keys])
+    enc = M.ModelBuilder.build_encoder(arch="resnet18dilated", fc_dim=512)
+    dec = M.ModelBuilder.build_decoder(arch="ppm_deepsup", fc_dim=512, num_class=K)
+    for name, net in (("encoder", enc), ("decoder", dec)):
+        names = {id(p): n for n, p in net.named_parameters()}
+        groups = ref_train.group_weight(net)
+        res["group_weight:%s:decay" % name] = np.array([names[id(p)] for p in groups[0]["params"]])
+        res["group_weight:%s:no_decay" % name] = np.array([names[id(p)] for p in groups[1]["params"]])
+        res["group_weight:%s:no_decay_wd" % name] = np.float64(groups[1]["weight_decay"])
+    cfg = ref_train.cfg
+    cfg.TRAIN.lr_encoder, cfg.TRAIN.lr_decoder, cfg.TRAIN.weight_decay = 0.002, 0.004, 1e-4
+    opts = ref_train.create_optimizers((enc, dec, None), cfg)
+    for name, opt in zip(("encoder", "decoder"), opts):
+        res["opt:%s:group_sizes" % name] = np.array([len(g["params"]) for g in opt.param_groups])
+        res["opt:%s:group_wd" % name] = np.array([g["weight_decay"] for g in opt.param_groups], dtype=np.float64)
+        res["opt:%s:group_lr0" % name] = np.array([g["lr"] for g in opt.param_groups], dtype=np.float64)
+        res["opt:%s:momentum" % name] = np.float64(opt.param_groups[0]["momentum"])
+    max_iters, iters = 900, [0, 1, 13, 450, 899]
+    trace = []
+    for it in iters:
+        ref_train.adjust_learning_rate(opts, it, cfg, max_iters)
+        trace.append([opts[0].param_groups[0]["lr"], opts[0].param_groups[1]["lr"], opts[1].param_groups[0]["lr"],
+                      opts[1].param_groups[1]["lr"], cfg.TRAIN.running_lr_encoder, cfg.TRAIN.running_lr_decoder])
+    res["lr:iters"], res["lr:max_iters"] = np.array(iters), np.int64(max_iters)
+    res["lr:trace"] = np.array(trace, dtype=np.float64)
+    res["lr:lr_pow"] = np.float64(cfg.TRAIN.lr_pow)
+    res["cfg:beta1"] = np.float64(cfg.TRAIN.beta1)
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, len(res), "arrays")
+
+
 def case_drivers(M, tag="drivers_reference"):
     """The host-side row of SURVEY.md 8(f)-2 pinned on the reference itself: Evaluator (utils.py:55-107), get_common
     (utils.py:37-53), parse_devices, create_optimizers / adjust_learning_rate (train_clip2.py:215-252), the argparse
@@ -1030,6 +1094,8 @@ def main():
         case_fixbn(M, "clip_ocr", "resnet50dilated", "r50_clip_ocr_fixbn")
     if want("drivers_reference"):
         case_drivers(M)
+    if want("frame_drivers_reference"):
+        case_frame_drivers(M)
 
 
 if __name__ == "__main__":

@@ -295,6 +295,28 @@ extern "C" int vspw_bn_fold_weights(const float* w, const float* cbias, const fl
     return vspw_launch_status();
 }
 
+// grid_sample(mode='nearest', zeros, align_corners=False) on the same grid: the temporal-consistency metric warps the NEXT
+// frame's label map onto the current frame (reference TC_cal.py:12-38).  ATen rounds the source coordinate with
+// nearbyint (ties to even); a source pixel outside the image gives 0.  One thread per output pixel and channel group.
+__global__ __launch_bounds__(256) void flowwarp_nearest_kernel(const float* __restrict__ x, const float* __restrict__ flow,
+                                                               float* __restrict__ y, int n, int h, int w, int c) {
+    const long long total = (long long)n * h * w;
+    long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; pix < total; pix += stride) {
+        const int ox = (int)(pix % w);
+        const long long r = pix / w;
+        const int oy = (int)(r % h);
+        const int img = (int)(r / h);
+        float px, py;
+        warp_coords(ox, oy, flow[pix * 2], flow[pix * 2 + 1], w, h, px, py);
+        const float rx = rintf(px), ry = rintf(py);
+        const bool ok = rx >= 0.f && rx <= (float)(w - 1) && ry >= 0.f && ry <= (float)(h - 1);
+        const float* src = ok ? x + (((size_t)img * h + (int)ry) * w + (int)rx) * c : nullptr;
+        for (int ch = 0; ch < c; ++ch) y[(size_t)pix * c + ch] = ok ? src[ch] : 0.f;
+    }
+}
+
 static int pixel_wave_grid(long long items) {
     long long g = (items + 3) / 4;
     if (g < 1) g = 1;
@@ -306,6 +328,14 @@ extern "C" int vspw_flowwarp_fwd(const float* x, const float* flow, float* y, in
                                  void* stream) {
     if (!x || !flow || !y || n <= 0 || h <= 0 || w <= 0 || c <= 0) return VSPW_EINVAL;
     hipLaunchKernelGGL(flowwarp_fwd_kernel, dim3(pixel_wave_grid((long long)n * h * w)), dim3(256), 0,
+                       vspw_stream(stream), x, flow, y, n, h, w, c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_flowwarp_nearest(const float* x, const float* flow, float* y, int n, int h, int w, int c,
+                                     void* stream) {
+    if (!x || !flow || !y || n <= 0 || h <= 0 || w <= 0 || c <= 0) return VSPW_EINVAL;
+    hipLaunchKernelGGL(flowwarp_nearest_kernel, dim3(vspw_stream_grid((long long)n * h * w, 256)), dim3(256), 0,
                        vspw_stream(stream), x, flow, y, n, h, w, c);
     return vspw_launch_status();
 }

@@ -693,6 +693,18 @@ def flowwarp(x, flo):
     return FlowWarpFn.apply(x, flo)
 
 
+def flowwarp_nearest(x, flo):
+    """flowwarp of TC_cal.py:12-38 (grid_sample mode='nearest'): label maps carried along the flow; no gradient."""
+    _require_gpu(x, "flowwarp_nearest")
+    x, flo = to_nhwc(x.detach()), to_nhwc(flo.detach())
+    n, c, h, w = x.shape
+    if tuple(flo.shape) != (n, 2, h, w):
+        raise RuntimeError("flowwarp_nearest: flow shape %s does not match input %s" % (tuple(flo.shape), tuple(x.shape)))
+    y = empty_nhwc(n, c, h, w, x.device)
+    _C.call("vspw_flowwarp_nearest", _p(x), _p(flo), _p(y), n, h, w, c, _stream())
+    return y
+
+
 class ChanBlendFn(torch.autograd.Function):
     """w0[c]*a + w1[c]*b (models/netwarp.py:201,216-217)."""
 

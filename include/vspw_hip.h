@@ -373,6 +373,9 @@ int vspw_chan_scale(const float* g, const float* w, float* out, long long rows, 
 int vspw_flowwarp_fwd(const float* x, const float* flow, float* y, int n, int h, int w, int c, void* stream);
 int vspw_flowwarp_bwd(const float* dy, const float* x, const float* flow, float* dx, float* dflow, int n, int h,
                       int w, int c, void* stream);
+/* The same warp with grid_sample(mode='nearest') - source coordinate rounded half-to-even, 0 outside the image: how the
+ * temporal-consistency metric carries the next frame's label map onto the current one (TC_cal.py:12-38, :112). */
+int vspw_flowwarp_nearest(const float* x, const float* flow, float* y, int n, int h, int w, int c, void* stream);
 
 /* ---------------------------------------------------------------- RAFT flow network (raft.hip) ----- */
 /* Forward-only kernels of the frozen RAFT that produces the flow consumed by vspw_flowwarp_fwd

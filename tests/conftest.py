@@ -22,7 +22,7 @@ def pytest_configure(config):
 _ORDER = ["test_ops_gpu", "test_ocr_blocks_gpu", "test_raft_gpu",          # kernels against fixtures / the oracle
           "test_models_gpu",                                                # model fixtures from the reference
           "test_fullsize_golden_gpu", "test_fullsize_gpu", "test_infer_fullsize_gpu",  # every BASELINE config, own size
-          "test_miou_gate_gpu", "test_data_gpu", "test_graph_gpu", "test_drivers_gpu", "test_frame_drivers_gpu",
+          "test_miou_gate_gpu", "test_data_gpu", "test_graph_gpu", "test_drivers_gpu", "test_frame_drivers_gpu", "test_tools_gpu",
           "test_sync_gpu", "test_bench_gpu"]
 
 

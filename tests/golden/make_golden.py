@@ -864,6 +864,51 @@ def case_frame_drivers(M, tag="frame_drivers_reference"):
     print(tag, len(res), "arrays")
 
 
+def _function_from_script(path, name):
+    """One top-level function of a reference SCRIPT (a file whose module body runs a whole job, so it cannot be imported):
+    its definition is compiled from the parsed file and executed in a fresh namespace, nothing else of the file runs."""
+    import ast
+
+    tree = ast.parse(open(os.path.join(REF, path)).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == name]
+    assert len(fn) == 1, (path, name)
+    ns = {"torch": torch, "nn": torch.nn, "np": np}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), path, "exec"), ns)
+    return ns[name]
+
+
+def case_metric_tools(tag="metric_tools_reference"):
+    """The evaluation-side scripts of the reference: TC_cal.py's nearest flow-warp (TC_cal.py:12-38) on label maps with
+    sub-pixel, half-integer (ties) and out-of-image displacements; VC_perclip.py's get_common (:7-24); the 480p target
+    size of change2_480p.py:17."""
+    res = {}
+    warp = _function_from_script("TC_cal.py", "flowwarp")
+    rs = np.random.RandomState(21)
+    for name, (h, w) in (("a", (23, 31)), ("b", (48, 64)), ("c", (17, 16))):
+        lab = rs.randint(0, 124, size=(2, 1, h, w)).astype(np.float32)
+        flo = (rs.randn(2, 2, h, w) * 3.0).astype(np.float32)
+        flo[0, :, :4] = np.round(flo[0, :, :4] * 2.0) / 2.0     # exact halves: nearbyint ties
+        flo[1, 0, -3:] += w                                     # far outside the image
+        flo[1, 1, :, :2] -= h
+        res["warp:%s:lab" % name], res["warp:%s:flow" % name] = lab, flo
+        res["warp:%s:out" % name] = warp(torch.from_numpy(lab), torch.from_numpy(flo)).numpy()
+    vc = _function_from_script("VC_perclip.py", "get_common")
+    h, w = 13, 17
+    gts = [rs.randint(0, 4, (h, w)) for _ in range(12)]
+    for t in range(1, 12):
+        keep = rs.rand(h, w) < 0.8
+        gts[t][keep] = gts[t - 1][keep]
+    preds = [np.where(rs.rand(h, w) < 0.85, g, rs.randint(0, 4, (h, w))) for g in gts]
+    res["vc:gt"], res["vc:pred"] = np.stack(gts), np.stack(preds)
+    for cn in (2, 5):
+        res["vc:accs%d" % cn] = np.array(vc(gts, preds, cn, h, w), dtype=np.float64)
+    sizes = [(1920, 1080), (1280, 720), (853, 480), (640, 360), (1000, 563), (720, 1280)]
+    res["size480:in"] = np.array(sizes)
+    res["size480:out"] = np.array([int(480 * ww / hh) for ww, hh in sizes])
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    print(tag, len(res), "arrays")
+
+
 def case_drivers(M, tag="drivers_reference"):
     """The host-side row of SURVEY.md 8(f)-2 pinned on the reference itself: Evaluator (utils.py:55-107), get_common
     (utils.py:37-53), parse_devices, create_optimizers / adjust_learning_rate (train_clip2.py:215-252), the argparse
@@ -1096,6 +1141,8 @@ def main():
         case_drivers(M)
     if want("frame_drivers_reference"):
         case_frame_drivers(M)
+    if want("metric_tools_reference"):
+        case_metric_tools()
 
 
 if __name__ == "__main__":

@@ -23,7 +23,7 @@ from . import optim as voptim
 from .config import cfg
 from .dataset2 import BaseDataset, BaseDataset_longclip, DeviceTransform, collate_raw
 from .models import ModelBuilder, SegmentationModule
-from .train_clip2 import str2bool
+from .train_clip2 import GraphedTrainStep, str2bool
 from .utils import AverageMeter, Evaluator, parse_devices, setup_logger
 
 
@@ -47,15 +47,29 @@ def train(segmentation_module, data_loader, optimizers, history, epoch, cfg, arg
         it_ += 1
         batch_data = feed(args, data, transform, it_)
         data_time.update(time.time() - tic)
-        segmentation_module.zero_grad()
         adjust_learning_rate(optimizers, i + (epoch - 1) * epoch_iters, cfg, max_iters)
-        loss, acc = segmentation_module(batch_data)
-        loss, acc = loss.mean(), acc.mean()
-        loss.backward()
-        if hasattr(segmentation_module, "finish_gradients"):
-            segmentation_module.finish_gradients()  # wait for the bucketed RCCL all-reduce
-        for optimizer in optimizers:
-            optimizer.step()
+        imgs, gts = [batch_data["img_data"]], [batch_data["seg_label"]]
+        graphed = getattr(args, "_graphed_step", None)
+        if getattr(args, "hip_graph", False) and graphed is None:
+            try:  # the whole step replayed as one hipGraph (train_clip2.GraphedTrainStep): a per-frame step is short
+                # enough for the host to be the bottleneck when it issues ~1 000 launches from Python
+                graphed = args._graphed_step = GraphedTrainStep(
+                    segmentation_module, optimizers, args, imgs, gts,
+                    feed=lambda im, gt: {"img_data": im[0], "seg_label": gt[0], "step": 0})
+            except Exception as e:  # state was restored by GraphedTrainStep: carry on launch by launch
+                log("hipGraph capture of the training step failed (%s: %s); running eagerly" % (type(e).__name__, e))
+                args.hip_graph = False
+        if graphed is not None and graphed.matches(imgs, gts):
+            loss, acc = graphed(imgs, gts)
+        else:
+            segmentation_module.zero_grad()
+            loss, acc = segmentation_module(batch_data)
+            loss, acc = loss.mean(), acc.mean()
+            loss.backward()
+            if hasattr(segmentation_module, "finish_gradients"):
+                segmentation_module.finish_gradients()  # wait for the bucketed RCCL all-reduce
+            for optimizer in optimizers:
+                optimizer.step()
         batch_time.update(time.time() - tic)
         tic = time.time()
         ave_total_loss.update(loss.data.item())
@@ -189,6 +203,9 @@ def main(cfg, gpus, args):
     transform = DeviceTransform(device)
     segmentation_module.cuda(device)
     optimizers = create_optimizers(nets, cfg)
+    if world > 1 and getattr(args, "hip_graph", False) and os.environ.get("VSPW_GRAPH_WITH_COLLECTIVES") != "1":
+        log("--hip_graph is ignored with %d ranks (set VSPW_GRAPH_WITH_COLLECTIVES=1 to capture anyway)" % world)
+        args.hip_graph = False
     if world > 1:
         args._work_stream = torch.cuda.Stream(device)
         args._work_stream.wait_stream(torch.cuda.current_stream(device))
@@ -242,7 +259,7 @@ def build_parser():
     return p
 
 
-EXTRA_FLAGS = ("syncbn_formula",)  # additions without a reference counterpart
+EXTRA_FLAGS = ("syncbn_formula", "hip_graph")  # additions without a reference counterpart (added in __main__)
 
 
 def prepare(args, cfg):
@@ -263,6 +280,8 @@ def prepare(args, cfg):
 if __name__ == "__main__":
     parser = build_parser()
     parser.add_argument("--syncbn_formula", default="reference", choices=["reference", "single"])
+    parser.add_argument("--hip_graph", action="store_true",
+                        help="replay the training step as one captured hipGraph (fixed crop / batch shapes)")
     args = parser.parse_args()
     gpus = prepare(args, cfg)
     logger = setup_logger(distributed_rank=int(os.environ.get("RANK", "0")))

@@ -90,27 +90,33 @@ class GraphedTrainStep(object):
     after them, so the run takes exactly the reference's sequence of updates - and, every kernel being order-independent,
     arrives at the same bits as the eager loop (tests/test_drivers_gpu.py).  Batches of another shape run eagerly."""
 
-    def __init__(self, module, optimizers, args, clip_imgs, clip_gts):
+    def __init__(self, module, optimizers, args, clip_imgs, clip_gts, feed=None):
+        """optimizers: one optimizer or several (train.py steps one per net); feed(imgs, gts) -> the feed_dict of one
+        step from the static tensors (default: this driver's make_batch)."""
         from . import ops
         from .graph import GraphedStep
 
         self.imgs = [t.clone() for t in clip_imgs]
         self.gts = [t.clone() for t in clip_gts]
-        self.optimizers = optimizers
+        opts = list(optimizers) if isinstance(optimizers, (list, tuple)) else [optimizers]
+        self.optimizers = opts
+        if feed is None:
+            feed = lambda imgs, gts: make_batch(args, imgs, gts, 0)  # noqa: E731
         inner = module.module if hasattr(module, "module") else module
         snap = {k: v.detach().clone() for k, v in inner.state_dict().items()}
-        had_momentum = {p: ("momentum_buffer" in optimizers.state[p]) for g in optimizers.param_groups
+        had_momentum = {p: (o, "momentum_buffer" in o.state[p]) for o in opts for g in o.param_groups
                         for p in g["params"]}
-        mom = {p: optimizers.state[p]["momentum_buffer"].clone() for p, h in had_momentum.items() if h}
+        mom = {p: o.state[p]["momentum_buffer"].clone() for p, (o, h) in had_momentum.items() if h}
 
         def step():
             module.zero_grad()
-            loss, acc = module(make_batch(args, self.imgs, self.gts, 0))
+            loss, acc = module(feed(self.imgs, self.gts))
             loss, acc = loss.mean(), acc.mean()
             loss.backward()
             if hasattr(module, "finish_gradients"):
                 module.finish_gradients()
-            optimizers.step()
+            for o in opts:
+                o.step()
             return loss, acc
 
         try:
@@ -123,9 +129,9 @@ class GraphedTrainStep(object):
             with torch.no_grad():
                 for k, v in inner.state_dict().items():
                     v.copy_(snap[k])
-                for p, h in had_momentum.items():
-                    if "momentum_buffer" in optimizers.state[p]:
-                        buf = optimizers.state[p]["momentum_buffer"]
+                for p, (o, h) in had_momentum.items():
+                    if "momentum_buffer" in o.state[p]:
+                        buf = o.state[p]["momentum_buffer"]
                         buf.copy_(mom[p]) if h else buf.zero_()  # zero-filled buffers = torch's first-step semantics
             ops.invalidate_inference_cache()
 
@@ -136,7 +142,8 @@ class GraphedTrainStep(object):
     def __call__(self, clip_imgs, clip_gts):
         for dst, src in zip(self.imgs + self.gts, list(clip_imgs) + list(clip_gts)):
             dst.copy_(src)
-        self.optimizers.set_lrs()
+        for o in self.optimizers:
+            o.set_lrs()
         return self.graph.replay()
 
 

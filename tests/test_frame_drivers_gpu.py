@@ -107,3 +107,52 @@ def test_train_checkpoint_eval(dev, tree, tmp_path, use_clip):
     for k in ("Acc", "mIoU", "fwIoU", "video_mIoU", "video_fwIoU"):
         assert 0.0 <= out[k] <= 1.0, (k, out[k])
     assert len(os.listdir(str(tmp_path / "pred" / "v_b"))) == 9  # one palette PNG per frame of the video
+
+
+def test_hip_graph_per_frame_loop_equals_the_eager_loop(dev, tmp_path):
+    """train.train with hip_graph (the step - both nets' SGDs included - captured once and replayed over static batch
+    buffers) against the plain loop: the same loss trace and bit-identical parameters, buffers and momentum of both
+    optimizers (Dropout2d disabled: the capture's warm-up advances the Philox offset)."""
+    import cvpr2021_vspw_implement_amd.train as T
+    from cvpr2021_vspw_implement_amd.config import cfg as base_cfg
+    from helpers import load_det, zero_dropout
+
+    here = os.path.dirname(os.path.abspath(T.__file__))
+    yaml = os.path.join(here, "config", "vsp-resnet18dilated-ppm_deepsup.yaml")
+
+    def run(hip_graph):
+        args = T.build_parser().parse_args(["--cfg", yaml, "--predir", "", "--totalepoch", "1", "--lr", "0.01",
+                                            "--gpus", "0"])
+        args.hip_graph = hip_graph
+        cfg = base_cfg.clone()
+        T.prepare(args, cfg)
+        mod, nets = T.build_module(cfg, args)
+        load_det(mod)
+        zero_dropout(mod)
+        mod.to(dev)
+        opts = T.create_optimizers(nets, cfg)
+        g = torch.Generator().manual_seed(12)
+        batches = [(torch.randn(3, 3, 40, 40, generator=g), torch.randint(0, args.num_class, (3, 1, 40, 40), generator=g).float())
+                   for _ in range(4)]
+
+        class Feed(object):  # stands in for loader + device transform: hands out the prepared per-frame batches
+            device = dev
+
+            def __call__(self, data, frames_as_batch=False):
+                return [data[0].to(dev)], [data[1].to(dev)]
+
+        hist = {"train": {"epoch": [], "loss": [], "acc": []}}
+        T.train(mod, batches, opts, hist, 1, cfg, args, Feed(), log=lambda *a: None)
+        torch.cuda.synchronize()
+        state = {k: v.detach().cpu().numpy() for k, v in mod.state_dict().items()}
+        mom = [o.state[p]["momentum_buffer"].cpu().numpy() for o in opts for grp in o.param_groups for p in grp["params"]
+               if "momentum_buffer" in o.state[p]]
+        return hist["train"]["loss"], state, mom, getattr(args, "_graphed_step", None)
+
+    l0, s0, m0, g0 = run(False)
+    l1, s1, m1, g1 = run(True)
+    assert g0 is None and g1 is not None
+    assert len(l0) == 4 and l0 == l1, (l0, l1)
+    for k in s0:
+        assert np.array_equal(s0[k], s1[k]), k
+    assert len(m0) == len(m1) > 0 and all(np.array_equal(a, b) for a, b in zip(m0, m1))

@@ -321,6 +321,17 @@ class TestDataset_clip(_TestBase):
         return self._sample(names, imagenames)
 
 
+class TwoDataset(torch.utils.data.Dataset):
+    """dataset2.py:1052-1246, imported by train.py:16 (`--usetwodata`: VSPW mixed with a second, ADE-style tree; every
+    script of the reference runs with USETWODATA=False).  Not part of the VSPW path: importable, raises at construction."""
+
+    def __init__(self, *a, **k):
+        raise NotImplementedError("dataset2.TwoDataset (--usetwodata) is outside the VSPW hot-path scope (SURVEY.md §8)")
+
+
+MultiScaleTrainDataset = TwoDataset
+
+
 def collate_raw(samples):
     """DataLoader collate_fn: keep the decoded samples as they are (the batch is assembled on the device)."""
     return list(samples)

@@ -191,7 +191,8 @@ def test_import_surface_of_the_reference_drivers():
     surface = {
         "config": ["cfg"],
         "dataset": ["TrainDataset"],
-        "dataset2": ["BaseDataset", "BaseDataset_clip", "TestDataset_clip", "BaseDataset_longclip", "TestDataset_longclip"],
+        "dataset2": ["BaseDataset", "BaseDataset_clip", "TestDataset_clip", "BaseDataset_longclip", "TestDataset_longclip",
+                     "TestDataset", "TwoDataset"],
         "models": ["ModelBuilder", "ClipWarpNet", "NetWarp", "ETC", "Non_local3d", "PropNet", "OurWarpMerge", "Clip_PSP",
                    "ClipOCRNet", "NetWarp_ocr", "ETC_ocr", "SegmentationModule"],
         "models.td4_psp.td4_psp": ["td4_psp"],

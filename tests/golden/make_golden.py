@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from oracle.det_init import det_input, det_labels, det_tensor  # noqa: E402
+from oracle.det_init import det_input, det_labels, det_sample_index, det_tensor  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 K = 124
@@ -909,6 +909,73 @@ def case_metric_tools(tag="metric_tools_reference"):
     print(tag, len(res), "arrays")
 
 
+def case_frame_trajectory(M, tag="frame_train_trajectory"):
+    """Five optimisation steps of the reference's per-frame training loop (train.py:58-92 with its own create_optimizers /
+    adjust_learning_rate / SegmentationModule, resnet18dilated + ppm_deepsup, B = 2 frames of 65 x 65, Dropout2d off) in
+    float32 and float64: loss / accuracy per step, every parameter's norm and the momentum-buffer norms at the end.  Pins
+    model + loss + two SGDs (momentum, decay / no-decay groups) + poly schedule JOINTLY over several updates."""
+    import_reference_drivers()
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        import train as ref_train  # noqa
+    finally:
+        os.chdir(cwd)
+    res = {}
+    steps, max_iters = 5, 12
+    # "f32" / "f64": the run itself; "p0".."p5": float32 runs whose first image carries a relative perturbation of 1e-7
+    # (one float32 ulp): how far rounding-sized differences carry a float32 trajectory of THIS loop - the yardstick
+    runs = [(torch.float32, "f32", None), (torch.float64, "f64", None)] + [(torch.float32, "p%d" % i, i) for i in range(6)]
+    for dt, name, pert in runs:
+        torch.manual_seed(0)
+        enc = M.ModelBuilder.build_encoder(arch="resnet18dilated", fc_dim=512)
+        dec = M.ModelBuilder.build_decoder(arch="ppm_deepsup", fc_dim=512, num_class=K)
+        mod = M.SegmentationModule(enc, dec, torch.nn.NLLLoss(ignore_index=255), 0.4)
+        load_det(mod)
+        zero_dropout(mod)
+        mod.to(dt).train()
+        cfg = ref_train.cfg
+        cfg.TRAIN.lr_encoder = cfg.TRAIN.lr_decoder = 0.002
+        cfg.TRAIN.weight_decay = 1e-4
+        opts = ref_train.create_optimizers((enc, dec, None), cfg)
+        losses, accs = [], []
+        for it in range(steps):
+            x = det_input("%s:img:%d" % (tag, it), (2, 3, 65, 65))
+            if pert is not None and it == 0:
+                x = x * (1.0 + 1e-7 * np.random.RandomState(900 + pert).randn(*x.shape)).astype(np.float32)
+            img = torch.from_numpy(x).to(dt)
+            lab = torch.from_numpy(det_labels("%s:lab:%d" % (tag, it), (2, 1, 65, 65), K))
+            mod.zero_grad()
+            ref_train.adjust_learning_rate(opts, it, cfg, max_iters)
+            loss, acc = mod({"img_data": img, "seg_label": lab})
+            loss = loss.mean()
+            loss.backward()
+            if it == 0 and pert is None:  # the first step's gradients: norms, and the values at 64 fixed positions each
+                g0 = [(k, p.grad.detach().double()) for k, p in mod.named_parameters()]
+                res[name + ":grad0_norms"] = np.array([float(g.norm()) for _, g in g0])
+                res[name + ":grad0_samples"] = np.stack([g.flatten()[det_sample_index(k, g.numel(), 64)].numpy()
+                                                         for k, g in g0])
+            for o in opts:
+                o.step()
+            losses.append(float(loss.detach()))
+            accs.append(float(acc.mean()))
+        res[name + ":loss"], res[name + ":acc"] = np.array(losses), np.array(accs)
+        names = [k for k, _ in mod.named_parameters()]
+        res["param_names"] = np.array(names)
+        res[name + ":param_norms"] = np.array([float(p.detach().double().norm()) for _, p in mod.named_parameters()])
+        res[name + ":momentum_norms"] = np.array([float(o.state[p]["momentum_buffer"].double().norm())
+                                                  for o in opts for g in o.param_groups for p in g["params"]])
+        if pert is None:
+            bn = mod.encoder.layer4[1].bn2
+            res[name + ":running_mean"] = bn.running_mean.double().numpy()
+            res[name + ":running_var"] = bn.running_var.double().numpy()
+    res["meta"] = np.array([steps, max_iters])
+    np.savez_compressed(os.path.join(OUT, tag + ".npz"), **res)
+    dev = np.stack([np.abs(res["p%d:loss" % i] - res["f64:loss"]) for i in range(6)])
+    print(tag, "loss f64", res["f64:loss"], "|f32 - f64|", np.abs(res["f32:loss"] - res["f64:loss"]),
+          "perturbed float32 runs: max |. - f64| per step", dev.max(0))
+
+
 def case_drivers(M, tag="drivers_reference"):
     """The host-side row of SURVEY.md 8(f)-2 pinned on the reference itself: Evaluator (utils.py:55-107), get_common
     (utils.py:37-53), parse_devices, create_optimizers / adjust_learning_rate (train_clip2.py:215-252), the argparse
@@ -1143,6 +1210,8 @@ def main():
         case_frame_drivers(M)
     if want("metric_tools_reference"):
         case_metric_tools()
+    if want("frame_train_trajectory"):
+        case_frame_trajectory(M)
 
 
 if __name__ == "__main__":

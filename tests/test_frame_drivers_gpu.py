@@ -156,3 +156,77 @@ def test_hip_graph_per_frame_loop_equals_the_eager_loop(dev, tmp_path):
     for k in s0:
         assert np.array_equal(s0[k], s1[k]), k
     assert len(m0) == len(m1) > 0 and all(np.array_equal(a, b) for a, b in zip(m0, m1))
+
+
+def test_five_training_steps_follow_the_reference_trajectory(dev):
+    """Model + loss + both SGDs (momentum, decay / no-decay groups) + poly schedule JOINTLY over five updates against
+    the reference's own per-frame training loop run in float64 (tests/golden/frame_train_trajectory.npz).  Yardstick:
+    the reference's float32 run and six float32 runs whose first image carries a one-ulp perturbation - how far
+    rounding-sized differences carry a float32 trajectory of this loop (5e-7 at step 0, 1e-4 at step 4).  Each step's
+    loss is held to 4 x the largest of those deviations, with a floor of 5e-6 relative: a single ReLU decision on a
+    pre-activation of 1e-6 - which the Winograd and the direct evaluation of one layer3 convolution take differently -
+    moves the upstream gradients by 8e-3 (one element of a 41 472-element map) and the next step's loss by 2e-5
+    (tools/diag/trajectory_probe{3,4,5}.py: every Winograd gradient call on the model's real operands is within 7.5e-7 of
+    float64; exactly two decisions differ between the two paths)."""
+    import cvpr2021_vspw_implement_amd.models as M
+    import cvpr2021_vspw_implement_amd.train as T
+    from cvpr2021_vspw_implement_amd.config import cfg as base_cfg
+    from helpers import K, load_det, zero_dropout
+    from oracle.det_init import det_input, det_labels
+
+    fx = golden("frame_train_trajectory")
+    steps, max_iters = (int(v) for v in fx["meta"])
+    tag = "frame_train_trajectory"
+    enc = M.ModelBuilder.build_encoder(arch="resnet18dilated", fc_dim=512)
+    dec = M.ModelBuilder.build_decoder(arch="ppm_deepsup", fc_dim=512, num_class=K)
+    mod = M.SegmentationModule(enc, dec, torch.nn.NLLLoss(ignore_index=255), 0.4)
+    load_det(mod)
+    zero_dropout(mod)
+    mod.to(dev).train()
+    cfg = base_cfg.clone()
+    cfg.TRAIN.lr_encoder = cfg.TRAIN.lr_decoder = 0.002
+    cfg.TRAIN.weight_decay = 1e-4
+    opts = T.create_optimizers((enc, dec, None), cfg)
+    losses, accs = [], []
+    for it in range(steps):
+        img = torch.from_numpy(det_input("%s:img:%d" % (tag, it), (2, 3, 65, 65))).to(dev)
+        lab = torch.from_numpy(det_labels("%s:lab:%d" % (tag, it), (2, 1, 65, 65), K)).to(dev)
+        mod.zero_grad()
+        T.adjust_learning_rate(opts, it, cfg, max_iters)
+        loss, acc = mod({"img_data": img, "seg_label": lab})
+        loss = loss.mean()
+        loss.backward()
+        for o in opts:
+            o.step()
+        losses.append(loss.item())
+        accs.append(acc.mean().item())
+    l32, l64 = fx["f32:loss"], fx["f64:loss"]
+    ens = np.stack([np.abs(fx[k + ":loss"] - l64) for k in ("f32", "p0", "p1", "p2", "p3", "p4", "p5")]).max(0)
+    err = np.abs(np.array(losses) - l64)
+    print("trajectory |hip - ref64|", list(err), "float32 ensemble max |. - ref64|", list(ens))
+    for t in range(steps):
+        gate = max(5e-6 * abs(l64[t]), 4.0 * ens[t])
+        assert err[t] <= gate, (t, losses[t], float(l64[t]), float(err[t]), gate)
+    assert err[0] <= 2e-6  # before any update: the forward pass alone
+    names = [str(n) for n in fx["param_names"]]
+    got = dict((k, float(p.detach().double().norm())) for k, p in mod.named_parameters())
+    members = ("f32", "p0", "p1", "p2", "p3", "p4", "p5")
+    ref = fx["f64:param_norms"]
+    gap = np.stack([np.abs(fx[k + ":param_norms"] - ref) for k in members]).max(0)
+    err = np.abs(np.array([got[k] for k in names]) - ref)
+    rel = err / ref
+    assert np.median(rel) <= max(4.0 * np.median(gap / ref), 1e-6), (float(np.median(rel)), float(np.median(gap / ref)))
+    assert rel.max() <= max(4.0 * (gap / ref).max(), 1e-4), (float(rel.max()), names[int(rel.argmax())])
+    mom = np.array([float(o.state[p]["momentum_buffer"].double().norm()) for o in opts for g in o.param_groups
+                    for p in g["params"]])
+    mref = fx["f64:momentum_norms"]
+    scale = np.maximum(mref, 1e-3 * mref.max())
+    mgap = np.stack([np.abs(fx[k + ":momentum_norms"] - mref) for k in members]).max(0) / scale
+    merr = np.abs(mom - mref) / scale
+    assert np.median(merr) <= max(4.0 * np.median(mgap), 1e-5), (float(np.median(merr)), float(np.median(mgap)))
+    bn = mod.encoder.layer4[1].bn2
+    for what, got_t in (("running_mean", bn.running_mean), ("running_var", bn.running_var)):
+        r64, r32 = fx["f64:" + what], fx["f32:" + what]
+        e = np.abs(got_t.cpu().numpy() - r64).max()
+        assert e <= max(8.0 * np.abs(r32 - r64).max(), 1e-5 * np.abs(r64).max()), (what, float(e), float(np.abs(r32 - r64).max()))
+    print("trajectory: hip", losses, "ref32", list(l32), "ref64", list(l64))

@@ -109,6 +109,39 @@ def test_train_checkpoint_eval(dev, tree, tmp_path, use_clip):
     assert len(os.listdir(str(tmp_path / "pred" / "v_b"))) == 9  # one palette PNG per frame of the video
 
 
+def test_per_frame_ocrnet_through_the_drivers(dev, tree, tmp_path):
+    """scripts/run_ocr.sh's path: train.py / test.py with the ocrnet_deepsup decoder (SpatialOCRNet) - one epoch on the
+    tiny tree (ResNet-50 through the config override the reference's `opts` allow), checkpoints, evaluation."""
+    import cvpr2021_vspw_implement_amd.test as E
+    import cvpr2021_vspw_implement_amd.train as T
+    from cvpr2021_vspw_implement_amd.config import cfg as base_cfg
+
+    save = str(tmp_path / "ck")
+    here = os.path.dirname(os.path.abspath(T.__file__))
+    yaml = os.path.join(here, "config", "vsp-resnet101dilated-ocr_deepsup.yaml")
+    args = T.build_parser().parse_args([
+        "--cfg", yaml, "--predir", "", "--dataroot", tree, "--saveroot", save, "--batchsize", "3", "--cropsize", "40",
+        "--trainfps", "3", "--totalepoch", "1", "--lr", "0.01", "--workers", "0", "--gpus", "0", "--validation", "false",
+        "MODEL.arch_encoder", "resnet50dilated"])
+    cfg = base_cfg.clone()
+    T.prepare(args, cfg)
+    assert cfg.MODEL.arch_decoder == "ocrnet_deepsup" and cfg.MODEL.arch_encoder == "resnet50dilated"
+    hist = T.main(cfg, [0], args)
+    assert len(hist["train"]["loss"]) >= 2 and all(np.isfinite(hist["train"]["loss"]))
+    dec_sd = torch.load(os.path.join(save, "decoder_epoch_1.pth"), map_location="cpu")
+    assert any(k.startswith("spatial_ocr_head.") for k in dec_sd) and any(k.startswith("dsn_head.") for k in dec_sd)
+    eargs = E.build_parser().parse_args([
+        "--cfg", yaml, "--dataroot", tree, "--split", "val", "--load_en", os.path.join(save, "encoder_epoch_1.pth"),
+        "--load_de", os.path.join(save, "decoder_epoch_1.pth"), "--batchsize", "2", "--saveroot", str(tmp_path / "pred"),
+        "MODEL.arch_encoder", "resnet50dilated"])
+    ecfg = base_cfg.clone()
+    E.prepare(eargs, ecfg)
+    eargs.workers = 0
+    eargs.dump_video_miou = False
+    out = E.main(ecfg, 0, eargs, log=lambda *a: None)
+    assert 0.0 <= out["mIoU"] <= 1.0 and 0.0 <= out["video_mIoU"] <= 1.0
+
+
 def test_hip_graph_per_frame_loop_equals_the_eager_loop(dev, tmp_path):
     """train.train with hip_graph (the step - both nets' SGDs included - captured once and replayed over static batch
     buffers) against the plain loop: the same loss trace and bit-identical parameters, buffers and momentum of both

@@ -351,7 +351,10 @@ extern "C" int vspw_wino_rows_prefer(const vspw_conv_desc* d, int channels, int 
     if (wr_forced > 0) return 1;
     const int tm = wr_tile_rows(wr_tile(p.T, rows, fused != 0));
     const long long wg = 4LL * (p.tpad / tm) * (rows / 128);
-    return fused ? (wg >= 350 && channels <= 2048) : (wg >= 700 && channels <= 512 && p.T >= 4096);
+    // (VSPW_WROWS_MAXROWS, experiments: widest output of the plain form.  Measured on TCB-OCR, whose head has a
+    // 2 048-row data gradient: limiting it to 1 024 rows is slower by 0.3-0.5 ms per step)
+    static const int max_rows = getenv("VSPW_WROWS_MAXROWS") ? atoi(getenv("VSPW_WROWS_MAXROWS")) : 1 << 30;
+    return fused ? (wg >= 350 && channels <= 2048) : (wg >= 700 && channels <= 512 && p.T >= 4096 && rows <= max_rows);
 }
 
 template <int FUSED>

@@ -107,7 +107,13 @@ def measured_traffic(kernel):
     a live one; None when no summary is present."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    def order(path):  # r04_final < r04_final2 < r05_a: round number, then the tag with a trailing number read as one
+        import re
+
+        m = re.match(r"r(\d+)_(.*?)(\d*)_pmc_summary\.json$", os.path.basename(path))
+        return (int(m.group(1)), m.group(2), int(m.group(3) or 0)) if m else (-1, os.path.basename(path), 0)
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), key=order)
     if not files:
         return None, None
     try:

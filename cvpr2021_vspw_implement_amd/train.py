@@ -191,8 +191,9 @@ def main(cfg, gpus, args):
     if world > 1:
         sampler = torch.utils.data.distributed.DistributedSampler(dataset_train, num_replicas=world, rank=rank,
                                                                   shuffle=True, seed=cfg.TRAIN.seed, drop_last=True)
-        val_sampler = torch.utils.data.distributed.DistributedSampler(dataset_val, num_replicas=world, rank=rank,
-                                                                      shuffle=False)
+        # every validation frame exactly once over the ranks (DistributedSampler would pad the split with repeats,
+        # which the summed confusion matrices would then count twice)
+        val_sampler = list(range(rank, len(dataset_val), world))
     loader_train = torch.utils.data.DataLoader(dataset_train, batch_size=args.batchsize // world,
                                                shuffle=sampler is None, sampler=sampler, num_workers=args.workers,
                                                drop_last=True, pin_memory=False, collate_fn=collate_raw)

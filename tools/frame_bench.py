@@ -19,10 +19,11 @@ def main():
     torch.manual_seed(304)
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     mode = sys.argv[2] if len(sys.argv) > 2 else "both"
+    yaml = sys.argv[3] if len(sys.argv) > 3 else "vsp-resnet101dilated-ppm_deepsup.yaml"  # e.g. ...-nonlocal2d.yaml (cfg 5a)
     if mode == "both":  # one process per mode: a capture after eager steps would meet their AccumulateGrad nodes
         import subprocess
 
-        outs = [json.loads(subprocess.run([sys.executable, os.path.abspath(__file__), str(B), m], capture_output=True,
+        outs = [json.loads(subprocess.run([sys.executable, os.path.abspath(__file__), str(B), m, yaml], capture_output=True,
                                           text=True, check=True).stdout.strip().splitlines()[-1]) for m in ("eager", "graph")]
         print(json.dumps({"workload": outs[0]["workload"], "eager_ms_per_step": outs[0]["ms_per_step"],
                           "hip_graph_ms_per_step": outs[1]["ms_per_step"],
@@ -31,7 +32,7 @@ def main():
         return
     S, K = 479, 124
     here = os.path.dirname(os.path.abspath(T.__file__))
-    args = T.build_parser().parse_args(["--cfg", os.path.join(here, "config", "vsp-resnet101dilated-ppm_deepsup.yaml"),
+    args = T.build_parser().parse_args(["--cfg", os.path.join(here, "config", yaml),
                                         "--predir", "", "--lr", "0.002"])
     cfg = base_cfg.clone()
     T.prepare(args, cfg)
@@ -66,7 +67,8 @@ def main():
         graph = GraphedStep(step, warmup=2)
         ms, out = timeit(graph.replay, 20)
         loss = out
-    print(json.dumps({"workload": "cfg2 per-frame PSPNet (R101 dilated + ppm_deepsup) train step, B=%d, 479x479" % B,
+    print(json.dumps({"workload": "per-frame %s + %s train step (train.py's model and optimizers), B=%d, 479x479"
+                      % (cfg.MODEL.arch_encoder, cfg.MODEL.arch_decoder, B),
                       "ms_per_step": round(ms, 2), "finite": bool(torch.isfinite(loss).item())}))
 
 

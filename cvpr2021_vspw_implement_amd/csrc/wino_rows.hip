@@ -387,10 +387,22 @@ extern "C" int vspw_wino_gemm_rows(const vspw_conv_desc* d, const float* v, int 
 
 // ... with V evaluated from the NHWC tensor src ([n][h][w][channels]: x, or dY for the data gradient) while the operand
 // is staged (vspw_wino_gemm_fused's operand form).
+extern "C" int vspw_wino_gemm_fused_rows_ex(const vspw_conv_desc* d, const float* src, long long ldx, int channels,
+                                            const float* u, int rows, float* tp, void* stream);
 extern "C" int vspw_wino_gemm_fused_rows(const vspw_conv_desc* d, const float* src, int channels, const float* u,
                                          int rows, float* tp, void* stream) {
+    return vspw_wino_gemm_fused_rows_ex(d, src, channels, channels, u, rows, tp, stream);
+}
+
+// ... with the source read at pixel stride ldx >= channels (the first `channels` channels of a wider NHWC buffer: the
+// flow network's concatenation buffers, cf. vspw_wino_gemm_fused_ex).
+extern "C" int vspw_wino_gemm_fused_rows_ex(const vspw_conv_desc* d, const float* src, long long ldx, int channels,
+                                            const float* u, int rows, float* tp, void* stream) {
     WinoRowsP p;
-    if (!src || !u || !tp || !wr_geom(d, channels, rows, p, true)) return VSPW_EINVAL;
+    if (!src || !u || !tp || ldx < channels || (ldx & 3) || ldx > 0x7fffffff || !wr_geom(d, channels, rows, p, true))
+        return VSPW_EINVAL;
+    if ((long long)(128 / p.tpi + 2) * d->h * d->w * ldx * 4 >= (1LL << 30)) return VSPW_EINVAL;
     p.a = src; p.u = u; p.tp = tp;
+    p.lds = (int)ldx;
     return wr_launch<1>(p, vspw_stream(stream));
 }

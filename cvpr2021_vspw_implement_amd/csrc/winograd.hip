@@ -503,6 +503,21 @@ extern "C" int vspw_wino_output_ex(const vspw_conv_desc* d, const float* m, int 
     return vspw_launch_status();
 }
 
+// vspw_wino_output_ex for the half-transformed planes (see vspw_wino_output_rows).
+extern "C" int vspw_wino_output_rows_ex(const vspw_conv_desc* d, const float* tp, long long tpad, int channels,
+                                        const float* bias, float* y, long long ldy, int act, void* stream) {
+    WinoGeom g;
+    const int cl4 = wino_cl4(channels);
+    if ((act != 0 && act != 1) || !wino_geom(d, g) || !tp || !y || cl4 == 0 || ldy < channels || (ldy & 3) ||
+        ldy > 0x7fffffff || tpad < g.T || tpad > 0x3fffffffLL)
+        return VSPW_EINVAL;
+    const int tb = wino_tb();
+    const dim3 grid(vspw_cdiv(g.T, tb), channels / 4 / cl4);
+    hipLaunchKernelGGL((wino_output_kernel<false, true>), grid, dim3(256), 0, vspw_stream(stream), tp, bias, y, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, act, g, channels, cl4, tb, (int)ldy, (int)tpad);
+    return vspw_launch_status();
+}
+
 extern "C" int vspw_wino_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream) {
     WinoGeom g;
     if (!wino_geom(d, g) || !dy || !dm || channels <= 0 || channels % 4) return VSPW_EINVAL;

@@ -13,6 +13,7 @@ C-ABI launches (csrc/raft.hip + vspw_conv2d_fwd_ex) on NHWC buffers:
   * the convex-upsampling mask is only evaluated for the last iteration (test_mode returns only that one).
 """
 import ctypes
+import os
 import math
 
 import torch
@@ -25,6 +26,9 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 
 
 # ------------------------------------------------------------------------------------------- parameter containers
+# the update block's Winograd convolutions through the row-fused GEMM where the grid fills the chip (see conv() below)
+_RAFT_WROWS = os.environ.get("VSPW_RAFT_WROWS", "1") == "1"
+
 class _ResidualBlock(nn.Module):
     """RAFT_core/extractor.py:6-56 (norm_fn 'instance' or 'batch'); norm3 is also downsample[1], as there."""
 
@@ -333,6 +337,16 @@ class RAFT(nn.Module):
                     m = wino_m[k] = torch.empty((16, T, k), **f32)
                 GEMM_FLOPS["total"] += 2.0 * rows * k * 9 * cc       # direct-convolution FLOPs this replaces
                 GEMM_FLOPS["executed"] = GEMM_FLOPS.get("executed", 0.0) + 2.0 * 16 * T * k * cc
+                # row-fused form (csrc/wino_rows.hip) once there is a workgroup per CU (480 x 856 frames: 272; measured
+                # 22.05 -> 21.76 ms per forward; NetWarp's 480 x 480 crops give 152 and stay with the 16 short GEMMs)
+                tpad = 0
+                if _RAFT_WROWS and k % 128 == 0 and 4 * ((T + 95) // 96) * (k // 128) >= 256:
+                    tpad = int(_C.query("vspw_wino_rows_tpad", ctypes.byref(d), cc, k, 1))
+                if tpad and tpad * 8 <= T * 16:  # (its 8 planes fit the 16-plane buffer)
+                    _C.call("vspw_wino_gemm_fused_rows_ex", ctypes.byref(d), x, ldx, cc, _p(u), k, _p(m), _stream())
+                    _C.call("vspw_wino_output_rows_ex", ctypes.byref(d), _p(m), tpad, k, _p(b), y, ldy,
+                            1 if act == ACT_RELU else 0, _stream())
+                    return
                 _C.call("vspw_wino_gemm_fused_ex", ctypes.byref(d), x, ldx, cc, _p(u), k, _p(m), _stream())
                 _C.call("vspw_wino_output_ex", ctypes.byref(d), _p(m), k, _p(b), y, ldy, 1 if act == ACT_RELU else 0,
                         _stream())

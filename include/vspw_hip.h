@@ -188,6 +188,12 @@ int vspw_wino_gemm_rows(const vspw_conv_desc* d, const float* v, int channels, c
                         void* stream);
 int vspw_wino_gemm_fused_rows(const vspw_conv_desc* d, const float* src, int channels, const float* u, int rows,
                               float* tp, void* stream);
+/* ... for operands that are channel slots of wider NHWC buffers (pixel strides ldx / ldy), cf. vspw_wino_gemm_fused_ex /
+ * vspw_wino_output_ex (RAFT_core/update.py:16-17,82-87). */
+int vspw_wino_gemm_fused_rows_ex(const vspw_conv_desc* d, const float* src, long long ldx, int channels, const float* u,
+                                 int rows, float* tp, void* stream);
+int vspw_wino_output_rows_ex(const vspw_conv_desc* d, const float* tp, long long tpad, int channels, const float* bias,
+                             float* y, long long ldy, int act, void* stream);
 int vspw_wino_output_rows(const vspw_conv_desc* d, const float* tp, long long tpad, int channels, const float* bias,
                           float* y, const float* relu_src, const float* bn_y, const float* bn_mean,
                           const float* bn_invstd, float* stat_part, const float* addend, int act, void* stream);

@@ -630,6 +630,29 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifdef VSPW_NT_CHUNK
+    // DIAGNOSTIC build only (tools/diag/parity_attrib.sh): two-level accumulation - every VSPW_NT_CHUNK K-tiles the
+    // running sums are folded into a second accumulator set, the summation shape of a k-blocked CPU GEMM.  Answers
+    // "how much of |hip - ref64| is the k-sequential order of the MFMA chain"; never shipped (112-128 more registers).
+    f32x16 acc2[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+    auto flush_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc2[i][j][r] += acc[i][j][r];
+                    acc[i][j][r] = 0.f;
+                }
+    };
+#endif
     NT_STAMP(1);
     NT_PRIO(0);
     if constexpr (TAPS > 0) {
@@ -684,6 +707,9 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
                 }
                 __syncthreads();
             }
+#ifdef VSPW_NT_CHUNK
+            flush_chunk();  // one 32-channel slab x TAPS taps = 288 k
+#endif
         }
     } else {
 #ifdef VSPW_NT_DBG
@@ -751,8 +777,19 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
             }
         }
         __syncthreads();
+#ifdef VSPW_NT_CHUNK
+        if ((kt + 1) % VSPW_NT_CHUNK == 0) flush_chunk();
+#endif
     }
     }  // tap-outer order
+#ifdef VSPW_NT_CHUNK
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
+#endif
     NT_STAMP(2);
     NT_PRIO(NT_PRIO_EDGE);
 #ifdef VSPW_NT_DBG

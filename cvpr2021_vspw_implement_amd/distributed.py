@@ -9,6 +9,7 @@ models/sync_batchnorm/comm.py): clips shard across ranks with no data-path excha
     SynchronizedBatchNorm semantics (ops.set_sync_bn).
 DataParallel averages the per-replica losses (train_clip2.py:98), so gradients are averaged, not summed.
 """
+import math
 import os
 
 import torch
@@ -235,6 +236,23 @@ class GradReducer:
             self.timer.setdefault("wait", []).append((w0, w1))
 
 
+def step_guard(module, loss_value):
+    """Called by the drivers where they read the loss (a device sync they pay anyway): a peer statistics exchange that
+    timed out has overwritten BatchNorm totals with NaN (exchange.hip) - raise instead of training on, and never let a
+    non-finite loss reach the running statistics / a checkpoint silently."""
+    if hasattr(module, "check_exchange"):
+        module.check_exchange()
+    if not math.isfinite(loss_value):
+        raise FloatingPointError("non-finite training loss (%r): aborting before it is written into a checkpoint" % (loss_value,))
+
+
+def checkpoint_barrier():
+    """After the rank-0-only checkpoint: the other ranks wait HERE (process-group timeout) instead of spinning in the
+    next step's peer exchange (VSPW_PEER_TIMEOUT_S, 20 s) while rank 0 is still inside torch.save."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
 class DataParallelOverRCCL(torch.nn.Module):
     """Drop-in for `nn.DataParallel(module)` + `patch_replication_callback` in the clip drivers: same call
     signature (`module(feed_dict)` -> (loss, acc)), one process per GPU underneath."""
@@ -264,6 +282,14 @@ class DataParallelOverRCCL(torch.nn.Module):
 
     def finish_gradients(self):
         self.reducer.wait()
+
+    def close(self):
+        """Release the peer-exchange arenas / IPC mappings and take the exchange out of ops (collective: call on every
+        rank, before destroy_process_group).  Building another wrapper afterwards starts from a clean state."""
+        if self.exchange is not None:
+            self.exchange.close()
+            self.exchange = None
+        ops.set_sync_bn(False)
 
     def check_exchange(self):
         """Raise if a peer statistics exchange timed out (device sync: call where the loss is read anyway)."""

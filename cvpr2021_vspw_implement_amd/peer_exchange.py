@@ -39,6 +39,7 @@ class PeerExchange:
         self.own = None
         self.opened = []
         self.exchanges = 0
+        self._closed = False
         lib = _C.load()
         nbytes = lib.vspw_xchg_arena_bytes(self.world, self.SLOT_DOUBLES)
         local_ok = nbytes > 0
@@ -152,6 +153,11 @@ class PeerExchange:
                                % self.timeout_s)
 
     def close(self):
+        """Collective over the group (like the constructor): EVERY rank runs the barrier, whether or not its own arena
+        allocation succeeded - a rank that skipped it would pair its next collective with the others' barrier."""
+        if self._closed:
+            return
+        self._closed = True
         lib = _C.load()
         try:
             torch.cuda.synchronize()
@@ -160,12 +166,12 @@ class PeerExchange:
         for p in self.opened:
             lib.vspw_xchg_close(_vp(p))
         self.opened = []
+        if self.world > 1 and dist.is_initialized():
+            try:
+                dist.barrier(group=self.group)  # peers have unmapped before the memory goes away
+            except Exception:  # noqa: BLE001
+                pass
         if self.own is not None:
-            if self.world > 1 and dist.is_initialized():
-                try:
-                    dist.barrier(group=self.group)  # peers have unmapped before the memory goes away
-                except Exception:  # noqa: BLE001
-                    pass
             lib.vspw_xchg_free(_vp(self.own))
             self.own = None
         self.ok = False

@@ -72,6 +72,7 @@ def train(segmentation_module, data_loader, optimizers, history, epoch, cfg, arg
                 optimizer.step()
         batch_time.update(time.time() - tic)
         tic = time.time()
+        vdist.step_guard(segmentation_module, loss.data.item())
         ave_total_loss.update(loss.data.item())
         ave_acc.update(acc.data.item() * 100)
         log("Epoch: [{}][{}/{}], Time: {:.2f}, Data: {:.2f}, lr_encoder: {:.6f}, lr_decoder: {:.6f}, "
@@ -110,17 +111,17 @@ def test(segmentation_module, loader, args, transform, log=print, world=1):
 
 def checkpoint(nets, optimizers, history, args, epoch):
     """train.py:167-188: encoder / decoder weights and both optimizers, one file each (rank 0 only)."""
-    if vdist.dist.is_initialized() and vdist.dist.get_rank() != 0:
-        return
-    print("Saving checkpoints...")
-    net_encoder, net_decoder, _crit = nets
-    if not os.path.exists(args.saveroot):
-        os.makedirs(args.saveroot)
-    torch.save(net_encoder.state_dict(), "{}/encoder_epoch_{}.pth".format(args.saveroot, epoch))
-    torch.save(net_decoder.state_dict(), "{}/decoder_epoch_{}.pth".format(args.saveroot, epoch))
-    optimizer_encoder, optimizer_decoder = optimizers
-    torch.save(optimizer_encoder.state_dict(), "{}/opt_encoder_epoch_{}.pth".format(args.saveroot, epoch))
-    torch.save(optimizer_decoder.state_dict(), "{}/opt_decoder_epoch_{}.pth".format(args.saveroot, epoch))
+    if not vdist.dist.is_initialized() or vdist.dist.get_rank() == 0:
+        print("Saving checkpoints...")
+        net_encoder, net_decoder, _crit = nets
+        if not os.path.exists(args.saveroot):
+            os.makedirs(args.saveroot)
+        torch.save(net_encoder.state_dict(), "{}/encoder_epoch_{}.pth".format(args.saveroot, epoch))
+        torch.save(net_decoder.state_dict(), "{}/decoder_epoch_{}.pth".format(args.saveroot, epoch))
+        optimizer_encoder, optimizer_decoder = optimizers
+        torch.save(optimizer_encoder.state_dict(), "{}/opt_encoder_epoch_{}.pth".format(args.saveroot, epoch))
+        torch.save(optimizer_decoder.state_dict(), "{}/opt_decoder_epoch_{}.pth".format(args.saveroot, epoch))
+    vdist.checkpoint_barrier()  # every rank: nobody starts the next step while rank 0 is still writing
 
 
 def group_weight(module):
@@ -224,6 +225,8 @@ def main(cfg, gpus, args):
             test(segmentation_module.module if hasattr(segmentation_module, "module") else segmentation_module,
                  loader_val, args, transform, log, world)
     log("Training Done!")
+    if hasattr(segmentation_module, "close"):
+        segmentation_module.close()  # peer-exchange arenas / IPC mappings (collective over the ranks)
     return history
 
 

@@ -184,6 +184,7 @@ def train(segmentation_module, data_loader, optimizers, history, epoch, cfg, arg
             optimizers.step()
         batch_time.update(time.time() - tic)
         tic = time.time()
+        vdist.step_guard(segmentation_module, loss.data.item())
         ave_total_loss.update(loss.data.item())
         ave_acc.update(acc.data.item() * 100)
         log("Epoch: [{}][{}/{}], Time: {:.2f}, Data: {:.2f}, lr_encoder: {:.6f}, lr_decoder: {:.6f}, "
@@ -245,14 +246,14 @@ def strip_module_prefix(sd):
 
 def checkpoint(opt, nets, history, args, epoch):
     """train_clip2.py:179-189: `<saveroot>/model_epoch_N.pth` and `opt_epoch_N.pth` (rank 0 only)."""
-    if vdist.dist.is_initialized() and vdist.dist.get_rank() != 0:
-        return
-    print("Saving checkpoints...")
-    if not os.path.exists(args.saveroot):
-        os.makedirs(args.saveroot)
-    mod = nets.module if hasattr(nets, "module") else nets
-    torch.save(_with_module_prefix(mod.state_dict()), "{}/model_epoch_{}.pth".format(args.saveroot, epoch))
-    torch.save(opt.state_dict(), "{}/opt_epoch_{}.pth".format(args.saveroot, epoch))
+    if not vdist.dist.is_initialized() or vdist.dist.get_rank() == 0:
+        print("Saving checkpoints...")
+        if not os.path.exists(args.saveroot):
+            os.makedirs(args.saveroot)
+        mod = nets.module if hasattr(nets, "module") else nets
+        torch.save(_with_module_prefix(mod.state_dict()), "{}/model_epoch_{}.pth".format(args.saveroot, epoch))
+        torch.save(opt.state_dict(), "{}/opt_epoch_{}.pth".format(args.saveroot, epoch))
+    vdist.checkpoint_barrier()  # every rank: nobody starts the next step while rank 0 is still writing
 
 
 def create_optimizers(model, cfg, args):
@@ -331,6 +332,8 @@ def main(cfg, gpus, args):
                 test(segmentation_module.module if hasattr(segmentation_module, "module") else segmentation_module,
                      args, transform, log, rank, world)
     log("Training Done!")
+    if hasattr(segmentation_module, "close"):
+        segmentation_module.close()  # peer-exchange arenas / IPC mappings (collective over the ranks)
     return history
 
 

@@ -177,11 +177,12 @@ def grads_pack(mod, suffix):
             "grad_samples" + suffix: np.concatenate(samples)}
 
 
-def case_train(M, kind, variant, tag, B=2):
-    """One training step (forward, loss, backward) at 479x479, Dropout2d off, float32 then float64."""
+def case_train(M, kind, variant, tag, B=2, T=None, only32=False):
+    """One training step (forward, loss, backward) at 479x479, Dropout2d off, float32 then float64 (only32: the
+    float64 re-run does not fit this container - cfg 5b at BASELINE's T=7 - and the float32 run alone is stored)."""
     t0 = time.time()
     clip = kind in ("clip_psp", "clip_ocr")
-    T = {"clip_psp": 5, "clip_ocr": 5, "nonlocal3d": 5, "netwarp": 2}.get(kind, 1)
+    T = T or {"clip_psp": 5, "clip_ocr": 5, "nonlocal3d": 5, "netwarp": 2}.get(kind, 1)
     mod, tap = build(M, kind, T)
     load_weights(mod, variant)
     sd = {k: v.clone() for k, v in mod.state_dict().items()}
@@ -191,7 +192,7 @@ def case_train(M, kind, variant, tag, B=2):
     res = {}
     store = {}
     h = G.hook_output(tap(mod), store, "l")
-    for suffix, cast in (("32", lambda t: t), ("64", lambda t: t.double())):
+    for suffix, cast in (("32", lambda t: t), ("64", lambda t: t.double()))[:1 if only32 else 2]:
         if suffix == "64":
             as64(mod, sd)
         mod.train()
@@ -214,6 +215,12 @@ def case_train(M, kind, variant, tag, B=2):
                                                                           res["acc" + suffix], time.time() - t0, rss_gb()),
               flush=True)
     h.remove()
+    if only32:
+        res["meta"] = np.array([kind, variant, str(T), str(B), str(S)])
+        np.savez_compressed(os.path.join(G.OUT, tag + ".npz"), **res)
+        print("%s: loss32 %.7f (float32 only); %.0f s, peak rss %.1f GB" % (tag, res["loss32"], time.time() - t0, rss_gb()),
+              flush=True)
+        return
     n32, n64 = res["grad_norms32"], res["grad_norms64"]
     rel = np.abs(n32 - n64) / np.maximum(n64, 1e-3 * n64.max())
     res["meta"] = np.array([kind, variant, str(T), str(B), str(S)])
@@ -242,6 +249,10 @@ def main():
             tag = "full_train_%s_%s_%s" % (cfg, kind, variant)
             if not only or tag in only or "train" in only:
                 case_train(M, kind, variant, tag)
+        # cfg 5b at BASELINE.json's own T=7 (25 200 positions, 2 x 2.54 GB affinity): float32 only
+        tag = "full_train_cfg5b_t7_nonlocal3d_%s" % variant
+        if not only or tag in only or "train" in only:
+            case_train(M, "nonlocal3d", variant, tag, T=7, only32=True)
 
 
 if __name__ == "__main__":

@@ -21,6 +21,7 @@ from oracle.det_init import damp_residual_gammas, det_input, det_labels, det_sam
 
 pytestmark = pytest.mark.gpu
 H, W, S = 480, 853, 479
+RAW_GATE = 2.0  # raw-weight variant: |hip - ref64| <= max(1e-3, RAW_GATE x |ref32 - ref64|)
 
 
 def _t(a, dev):
@@ -122,20 +123,19 @@ def test_480p_inference_against_reference_vectors(dev, kind, cfg, variant):
     am = probs.argmax(1).astype(np.uint8)
     flips = am != fx["argmax32"]
     margin = fx["margin32"].astype(np.float32)
+    tol = 1e-3 if variant == "damped" else max(1e-3, RAW_GATE * own)
+    decisive = margin > 2 * tol
+    print("%s %s 480x853 vs the reference: |logit| max %.2f; |ref32 - ref64| %.2e; |hip - ref32| %.2e; |hip - ref64| %.2e "
+          "(tol %.1e, excess over the reference's own fp32 %.2fx); probs %.2e; arg-max: %d of %d pixels differ (reference fp32 vs its own fp64: %d), %d decisive"
+          % (cfg, variant, float(fx["logits_absmax"]), own, e32, e64, tol, e64 / own, ep, flips.sum(), flips.size,
+             (fx["argmax32"] != fx["argmax64"]).sum(), (flips & decisive).sum()))
     if variant == "damped":
-        tol = 1e-3  # north_star, unwidened
-        assert own < 5e-4, own
+        assert own < 5e-4, own  # north_star, unwidened
         assert e32 <= tol, (e32, tol)
         assert float(np.abs(unfolded - fx["logits32_sub"]).max()) <= tol
     else:
-        tol = max(1e-3, 2.0 * own)
         assert e64 <= tol, (e64, tol)
         assert float(np.abs(unfolded.astype(np.float64) - fx["logits64_sub"]).max()) <= tol
-    decisive = margin > 2 * tol
-    print("%s %s 480x853 vs the reference: |logit| max %.2f; |ref32 - ref64| %.2e; |hip - ref32| %.2e; |hip - ref64| %.2e "
-          "(tol %.1e); probs %.2e; arg-max: %d of %d pixels differ (reference fp32 vs its own fp64: %d), %d decisive"
-          % (cfg, variant, float(fx["logits_absmax"]), own, e32, e64, tol, ep, flips.sum(), flips.size,
-             (fx["argmax32"] != fx["argmax64"]).sum(), (flips & decisive).sum()))
     assert ep <= 1e-3, ep
     assert np.abs(probs.sum(1) - 1).max() < 1e-5
     assert (flips & decisive).sum() == 0
@@ -169,16 +169,11 @@ def test_479_training_step_against_reference_vectors(dev, kind, cfg, variant):
     l32, l64 = float(fx["loss32"]), float(fx["loss64"])
     lh = loss.item()
     own_loss = abs(l32 - l64) / abs(l64)
-    assert abs(lh - l64) <= max(2e-5, 2 * own_loss) * abs(l64), (lh, l32, l64)
-    assert abs(acc.item() - float(fx["acc64"])) <= max(1e-3, 2 * abs(float(fx["acc32"]) - float(fx["acc64"])))
     # train-mode logits of the head
     sub = store["l"][: fx["logits32_sub"].shape[0], :, ::2, ::2]  # (the fixture keeps the first 4 images)
     own_l = float(np.abs(fx["logits32_sub"] - fx["logits64_sub"]).max())
     e_l32 = float(np.abs(sub - fx["logits32_sub"]).max())
     e_l64 = float(np.abs(sub - fx["logits64_sub"]).max())
-    assert e_l64 <= max(1e-3, 2 * own_l), (e_l64, own_l)
-    if own_l < 5e-4:
-        assert e_l32 <= 1e-3, e_l32  # north_star as written
     # running statistics after the step (momentum 0.1, unbiased variance)
     mods = dict(mod.named_modules())
     for key in fx.files:
@@ -212,11 +207,97 @@ def test_479_training_step_against_reference_vectors(dev, kind, cfg, variant):
     es_h, es_o = np.array(es_h), np.array(es_o)
     st = lambda v: "median %.2e p99 %.2e max %.2e" % (np.median(v), np.percentile(v, 99), v.max())  # noqa: E731
     print("%s %s 479x479 step vs the reference: loss hip %.7f ref32 %.7f ref64 %.7f; logits |hip-ref32| %.2e |hip-ref64| "
-          "%.2e (|ref32-ref64| %.2e)\n  grad norms, rel. to ref64:   HIP %s | reference fp32 %s\n  grad samples, rel. L2:       "
+          "%.2e (|ref32-ref64| %.2e, excess %.2fx)\n  grad norms, rel. to ref64:   HIP %s | reference fp32 %s\n  grad samples, rel. L2:       "
           "HIP %s | reference fp32 %s"
-          % (cfg, variant, lh, l32, l64, e_l32, e_l64, own_l, st(rel_h), st(rel_o), st(es_h), st(es_o)))
+          % (cfg, variant, lh, l32, l64, e_l32, e_l64, own_l, e_l64 / own_l, st(rel_h), st(rel_o), st(es_h), st(es_o)))
+    assert abs(lh - l64) <= max(2e-5, 2 * own_loss) * abs(l64), (lh, l32, l64)
+    assert abs(acc.item() - float(fx["acc64"])) <= max(1e-3, 2 * abs(float(fx["acc32"]) - float(fx["acc64"])))
+    assert e_l64 <= max(1e-3, RAW_GATE * own_l), (e_l64, own_l)
+    if own_l < 5e-4:
+        assert e_l32 <= 1e-3, e_l32  # north_star as written
     # the maximum over ~680 tensors of ONE rounding realisation is a heavy-tailed statistic (measured on the raw cfg 5a
     # case: 2.3x the reference's own): factor 3 there, 2 on the median and the 99th percentile
     for what, f, k in (("median", np.median, 2.0), ("p99", lambda v: np.percentile(v, 99), 2.0), ("max", np.max, 3.0)):
         assert f(rel_h) <= max(1e-3, k * f(rel_o)), ("norms", what, f(rel_h), f(rel_o))
         assert f(es_h) <= max(1e-3, k * f(es_o)), ("samples", what, f(es_h), f(es_o))
+
+
+@pytest.mark.parametrize("variant", ["damped", "raw"])
+def test_479_training_step_cfg5b_at_T7_against_reference_fp32(dev, variant):
+    """cfg 5b at BASELINE.json's own clip length: Non_local3d over T=7 frames (25 200 positions, 2 x 2.54 GB affinity that
+    the HIP path never materialises), one training step at B=2 / 479x479 against the REFERENCE's float32 run
+    (full_train_cfg5b_t7_*: the float64 re-run needs > 64 GB and does not fit the build container, so there is no
+    |ref32 - ref64| of its own: the yardstick is the T=5 fixture's, same model, same variant).  Two float32
+    realisations are compared, each `own` from the truth: |hip - ref32| <= (1 + RAW_GATE) x own, and the damped
+    variant's logits meet north_star's flat 1e-3 directly."""
+    fx = golden("full_train_cfg5b_t7_nonlocal3d_%s" % variant)
+    y5 = golden("full_train_cfg5b_nonlocal3d_%s" % variant)  # yardstick: the reference's own fp32-vs-fp64 at T=5
+    T, B = 7, 2
+    mod, tap = _module("nonlocal3d", T)
+    _load(mod, variant)
+    mod.to(dev).train()
+    name = "train479:nonlocal3d"
+    frames = [_t(det_input("%s:%d" % (name, t), (B, 3, S, S)), dev) for t in range(T)]
+    labels = [_t(det_labels("%s:%d" % (name, t), (B, 1, S, S), K), dev) for t in range(T)]
+    store = {}
+    hk = tap(mod).register_forward_hook(lambda m, i, o: store.__setitem__("l", o.detach().float().cpu().numpy()))
+    loss, acc = mod(_feed(frames, labels, False, "nonlocal3d"))
+    hk.remove()
+    loss.backward()
+    torch.cuda.synchronize()
+    lh, l32 = loss.item(), float(fx["loss32"])
+    own_loss = abs(float(y5["loss32"]) - float(y5["loss64"])) / abs(float(y5["loss64"]))
+    sub = store["l"][: fx["logits32_sub"].shape[0], :, ::2, ::2]
+    own_l = float(np.abs(y5["logits32_sub"] - y5["logits64_sub"]).max())
+    e_l32 = float(np.abs(sub - fx["logits32_sub"]).max())
+    names = [str(n) for n in fx["grad_names"]]
+    grads = {k: p.grad for k, p in mod.named_parameters() if p.grad is not None}
+    assert set(names) == set(grads), sorted(set(names) ^ set(grads))[:5]
+    n32 = fx["grad_norms32"]
+    scale = float(n32.max())
+    nh = np.array([float(grads[k].double().norm()) for k in names])
+    rel_h = np.abs(nh - n32) / np.maximum(n32, 1e-3 * scale)
+    y_n32, y_n64 = y5["grad_norms32"], y5["grad_norms64"]
+    rel_y = np.abs(y_n32 - y_n64) / np.maximum(y_n64, 1e-3 * float(y_n64.max()))
+    s32, off, es_h = fx["grad_samples32"].astype(np.float64), 0, []
+    for k in names:
+        g = grads[k].detach().contiguous().view(-1)
+        idx = det_sample_index(k, g.numel())
+        v = g[_t(idx, dev)].double().cpu().numpy()
+        r32 = s32[off:off + len(idx)]
+        off += len(idx)
+        floor = 1e-3 * scale * (len(idx) / g.numel()) ** 0.5
+        es_h.append(float(np.linalg.norm(v - r32)) / max(float(np.linalg.norm(r32)), floor))
+    es_h = np.array(es_h)
+    ys32, ys64, off, es_y = y5["grad_samples32"].astype(np.float64), y5["grad_samples64"], 0, []
+    y_names = [str(n) for n in y5["grad_names"]]
+    assert y_names == names
+    y_scale = float(y_n64.max())
+    for k in names:
+        n_el = grads[k].numel()
+        idx = det_sample_index(k, n_el)
+        r64, r32 = ys64[off:off + len(idx)], ys32[off:off + len(idx)]
+        off += len(idx)
+        floor = 1e-3 * y_scale * (len(idx) / n_el) ** 0.5
+        es_y.append(float(np.linalg.norm(r32 - r64)) / max(float(np.linalg.norm(r64)), floor))
+    es_y = np.array(es_y)
+    st = lambda v: "median %.2e p99 %.2e max %.2e" % (np.median(v), np.percentile(v, 99), v.max())  # noqa: E731
+    print("cfg5b %s T=7 479x479 step vs the reference's fp32: loss hip %.7f ref32 %.7f; acc hip %.5f ref32 %.5f; logits "
+          "|hip-ref32| %.2e (T=5 yardstick |ref32-ref64| %.2e)\n  grad norms, rel. to ref32:   HIP %s | yardstick %s\n"
+          "  grad samples, rel. L2:       HIP %s | yardstick %s"
+          % (variant, lh, l32, acc.item(), float(fx["acc32"]), e_l32, own_l, st(rel_h), st(rel_y), st(es_h), st(es_y)))
+    two = 1.0 + RAW_GATE  # two float32 realisations, each within its own distance of the truth
+    assert abs(lh - l32) <= max(2e-5, two * own_loss) * abs(l32), (lh, l32)
+    assert abs(acc.item() - float(fx["acc32"])) <= 1e-3
+    if variant == "damped":
+        assert e_l32 <= 1e-3, e_l32  # north_star as written
+    else:
+        assert e_l32 <= max(1e-3, two * own_l), (e_l32, own_l)
+    for key in fx.files:
+        if key.startswith("running_mean:") or key.startswith("running_var:"):
+            what, bn = key.split(":")
+            got = getattr(dict(mod.named_modules())[bn], what).detach().cpu().numpy()
+            assert np.abs(got - fx[key]).max() <= 1e-4 * max(1.0, np.abs(fx[key]).max()), key
+    for what, f, k in (("median", np.median, 3.0), ("p99", lambda v: np.percentile(v, 99), 3.0), ("max", np.max, 4.0)):
+        assert f(rel_h) <= max(1e-3, k * f(rel_y)), ("norms", what, f(rel_h), f(rel_y))
+        assert f(es_h) <= max(1e-3, k * f(es_y)), ("samples", what, f(es_h), f(es_y))

@@ -85,6 +85,10 @@ struct IgemmNT {
     // ow = 1; wino_d = dilation (0: off), wino_th x wino_tw = tiles per dilation sub-grid.  The grid is x-only:
     // 16 batches fastest, so that the 16 transforms of a tile's patch are read while it is L2-resident.
     int wino_d, wino_th, wino_tw;
+    // Two-level accumulation (CHUNK variants of the v2 pointwise kernel): every chunk_tiles K-tiles the running sums are
+    // folded into the output tile and the accumulators restart from zero; the epilogue adds the parked partial sums.
+    // 0 = one k-sequential chain.  See vspw_set_accum_chunk.
+    int chunk_tiles;
 #ifdef VSPW_NT_DBG
     int dbg;  // diagnostic builds only (tools/diag/nt_exposed.py): 1 = no epilogue memory traffic, 2 = no K loop
 #endif
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT pin) {
 // One output tile.  vb_in = tile index of this workgroup (already XCD-remapped), batch_idx = batch of a batched GEMM,
 // stamp_slot = slot of the diagnostic stamps.  Called once per workgroup by igemm_nt_v2_kernel and in a loop by the
 // persistent variant below.
-template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS, int AFF>
+template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS, int AFF, int CHUNK = 0>
 __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, int batch_idx, int stamp_slot) {
     IgemmNT p = pin;
     if (AFF != 4 && pin.batch > 1) {
@@ -384,6 +388,8 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
     static_assert(TAPS == 0 || (NBUF == 1 && MODE != 2), "tap-inner order: single LDS buffer, non-pointwise");
     static_assert(!AFF || (MODE == 2 && NBUF == 1), "transformed A operand: pointwise, single LDS buffer");
     static_assert(AFF != 4 || WM * WN <= 3, "Winograd operand: 4 staged float4 per row - the 96- / 64-row tiles only");
+    static_assert(!CHUNK || (MODE == 2 && TAPS == 0 && AFF != 4), "two-level accumulation: plain pointwise K loop only");
+    static_assert(!CHUNK || NBUF == 1 || 32 * WM * WGM >= 128, "flush scratch of 4 waves must fit ONE operand buffer");
     // AFF 1: A = coef0*src + coef1*src2 + coef2 (BatchNorm-backward apply); AFF 2: A = relu(coef0*src + coef1 + src2);
     // AFF 3: A = relu(coef0*src + coef1) (no residual)
     // (BatchNorm-forward apply + residual + ReLU of the producing node), also stored to zout
@@ -630,7 +636,77 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-#ifdef VSPW_NT_CHUNK
+    // ---- two-level accumulation (CHUNK) ----
+    // A k-sequential fp32 chain of K terms carries a rounding error ~ eps*sqrt(K/2) of the result; summed as K/b chains
+    // of b terms it is ~ eps*sqrt(b/2 + K/(2b)) (the shape of a k-blocked CPU GEMM, which is what the reference runs).
+    // Measured on the raw-weight full-size fixtures (profiles/r05_parity_attrib.log): the k-sequential chains of the
+    // K >= 1024 pointwise convolutions were the whole 1.3-1.5x excess of |hip - ref64| over the reference's own
+    // |ref32 - ref64|; Winograd on / off made no difference.  A second accumulator set costs a resident workgroup per CU,
+    // so the partial sums are parked where they belong anyway: every chunk_tiles K-tiles the block is added into the
+    // OUTPUT tile (first flush: = chain [+ the caller's addend]) through the epilogue's 16-byte LDS-transposed path and
+    // the accumulators restart from zero; the final epilogue then takes dst as its addend.  Same lanes, same addresses,
+    // one workgroup per tile: plain loads / stores, deterministic.
+    const int nk_all = p.kdim / BK;
+    const bool chunked = CHUNK && p.chunk_tiles > 0 && nk_all > p.chunk_tiles;
+    auto flush_partial = [&](const float* prev, float* scr_base) {
+        // (opaque copies: keeps the compiler from hoisting the flush's address arithmetic out of the K loop, where it
+        // would be spilled for the whole loop's duration)
+        int m0 = tile_m * TM, n0 = tile_n * TN;
+        asm volatile("" : "+s"(m0), "+s"(n0));
+        if (interior) {
+            float* scr = scr_base + wave * (32 * LDA);
+            const int erow = lane >> 3, ec4 = (lane & 7) * 4;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int col = n0 + wn * 32 * WN + j * 32 + ec4;
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    const size_t e0 = (size_t)(m0 + wm * 32 * WM + i * 32 + erow) * p.ldd + col;
+                    const size_t estep = (size_t)8 * p.ldd;
+                    f32x4 ad[4];
+                    if (prev != nullptr) {
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) ad[rq] = *reinterpret_cast<const f32x4*>(prev + e0 + rq * estep);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        scr[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDA + l31] = acc[i][j][r];
+                        acc[i][j][r] = 0.f;
+                    }
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        f32x4 o = *reinterpret_cast<const f32x4*>(&scr[(rq * 8 + erow) * LDA + ec4]);
+                        if (prev != nullptr) o += ad[rq];
+                        *reinterpret_cast<f32x4*>(p.dst + e0 + rq * estep) = o;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int col = n0 + wn * 32 * WN + j * 32 + l31;
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (col < p.nout && row < p.m) {
+                            float v = acc[i][j][r];
+                            if (prev != nullptr) v += prev[(size_t)row * p.ldd + col];
+                            p.dst[(size_t)row * p.ldd + col] = v;
+                        }
+                        acc[i][j][r] = 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();  // the scratch is operand space: nobody stages the next tile into it before every wave is done
+    };
+    (void)flush_partial;
+    int chunk_left = chunked ? p.chunk_tiles : 0x7fffffff;
+    bool flushed = false;
+#if defined(VSPW_NT_CHUNK) || defined(VSPW_NT_CHUNK_TAPS)
     // DIAGNOSTIC build only (tools/diag/parity_attrib.sh): two-level accumulation - every VSPW_NT_CHUNK K-tiles the
     // running sums are folded into a second accumulator set, the summation shape of a k-blocked CPU GEMM.  Answers
     // "how much of |hip - ref64| is the k-sequential order of the MFMA chain"; never shipped (112-128 more registers).
@@ -706,10 +782,10 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
                     }
                 }
                 __syncthreads();
-            }
-#ifdef VSPW_NT_CHUNK
-            flush_chunk();  // one 32-channel slab x TAPS taps = 288 k
+#ifdef VSPW_NT_CHUNK_TAPS
+                if ((cs * TAPS + t + 1) % VSPW_NT_CHUNK_TAPS == 0) flush_chunk();  // (9 = one 32-channel slab = 288 k)
 #endif
+            }
         }
     } else {
 #ifdef VSPW_NT_DBG
@@ -777,12 +853,22 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
             }
         }
         __syncthreads();
+        if constexpr (CHUNK) {
+            if (--chunk_left == 0 && kt + 1 < nk) {  // (uniform) tile kt's operand buffer is dead: the flush scratch
+                flush_partial(flushed ? p.dst : p.addend, As[cur]);
+                flushed = true;
+                chunk_left = p.chunk_tiles;
+            }
+        }
 #ifdef VSPW_NT_CHUNK
         if ((kt + 1) % VSPW_NT_CHUNK == 0) flush_chunk();
 #endif
     }
     }  // tap-outer order
-#ifdef VSPW_NT_CHUNK
+    if constexpr (CHUNK) {
+        if (flushed) p.addend = p.dst;  // the epilogue adds the parked partial sums (they already hold the caller's addend)
+    }
+#if defined(VSPW_NT_CHUNK) || defined(VSPW_NT_CHUNK_TAPS)
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -1001,10 +1087,10 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
 #endif
 }
 
-template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, int AFF = 0>
+template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, int AFF = 0, int CHUNK = 0>
 __global__ __launch_bounds__(256, NT_V2_BOUNDS(WM, WN, MODE, NBUF, TAPS, AFF)) void igemm_nt_v2_kernel(IgemmNT pin) {
-    igemm_nt_v2_body<WGM, WM, WN, MODE, NBUF, TAPS, AFF>(pin, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y,
-                                                         blockIdx.y * gridDim.x + blockIdx.x);
+    igemm_nt_v2_body<WGM, WM, WN, MODE, NBUF, TAPS, AFF, CHUNK>(pin, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y,
+                                                                blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // Persistent variant (short-K pointwise GEMMs): gridDim.x = resident workgroup slots (a multiple of 8), each workgroup
@@ -1095,26 +1181,57 @@ static bool launch_nt_persist(const IgemmNT& p, int tm, int tn, int fold, hipStr
     return true;
 }
 
+// Process-wide summation policy of the K >= 2*chunk pointwise GEMMs (see igemm_nt_v2_body, "two-level accumulation"):
+// chunk length in k (multiple of 32); 0 = one k-sequential chain.  Default 256, VSPW_ACCUM_CHUNK overrides it at load.
+static int g_accum_chunk = -1;
+static int accum_chunk() {
+    if (g_accum_chunk < 0) g_accum_chunk = getenv("VSPW_ACCUM_CHUNK") ? atoi(getenv("VSPW_ACCUM_CHUNK")) / BK * BK : 256;
+    return g_accum_chunk;
+}
+extern "C" int vspw_set_accum_chunk(int k) {
+    if (k < 0 || k % BK != 0) return VSPW_EINVAL;
+    g_accum_chunk = k;
+    return VSPW_OK;
+}
+extern "C" int vspw_get_accum_chunk(void) { return accum_chunk(); }
+
+// pointwise (MODE 2) launch of one A-operand flavour (AFF 0-3), with / without two-level accumulation
+template <int A, int CH>
+static void launch_nt_pw(const IgemmNT& p, int cfg, hipStream_t st) {
+    if (cfg == 22) {
+        int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
+        // measured: short reductions (K <= 1024, i.e. the 1x1 convs) gain ~10 % from the higher residency of the
+        // single-buffer variant (3 workgroups/CU); long ones gain 2-5 % from the second buffer (one barrier per tile)
+        static const int nbuf1_max_k = getenv("VSPW_NBUF1_MAXK") ? atoi(getenv("VSPW_NBUF1_MAXK")) : 1024;
+        if constexpr (A == 0) {
+            if (!CH && p.kdim <= nbuf1_max_k && launch_nt_persist<2, 2, 2, 0>(p, 128, 128, p.batch, st)) return;
+            if (p.kdim > nbuf1_max_k) {
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, 2, 2, 0, 0, CH>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+                return;
+            }
+        }
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, 2, 1, 0, A, CH>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+    } else if (cfg == 31) {
+        if constexpr (A == 0) {
+            if (!CH && launch_nt_persist<1, 3, 1, 0>(p, 96, 128, p.batch, st)) return;
+        }
+        int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, 2, 1, 0, A, CH>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+    } else if (cfg == 12) {
+        int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, 2, 1, 0, A, CH>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+    } else if (cfg == 21) {
+        int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, 2, 1, 0, A, CH>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+    } else {
+        int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
+        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, 2, 1, 0, A, CH>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+    }
+}
+
 template <int MODE>
 static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
     if constexpr (MODE == 2) {
-#define NT_AFF_LAUNCH(A)                                                                                              \
-    if (cfg == 22) {                                                                                                  \
-        int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);                                                     \
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, 2, 1, 0, A>), dim3(tiles, p.batch), dim3(256), 0, st, p);              \
-    } else if (cfg == 31) {                                                                                           \
-        int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);                                                      \
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, 2, 1, 0, A>), dim3(tiles, p.batch), dim3(256), 0, st, p);              \
-    } else if (cfg == 12) {                                                                                           \
-        int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);                                                      \
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, 2, 1, 0, A>), dim3(tiles, p.batch), dim3(256), 0, st, p);              \
-    } else if (cfg == 21) {                                                                                           \
-        int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);                                                      \
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, 2, 1, 0, A>), dim3(tiles, p.batch), dim3(256), 0, st, p);              \
-    } else {                                                                                                          \
-        int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);                                                       \
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, 2, 1, 0, A>), dim3(tiles, p.batch), dim3(256), 0, st, p);              \
-    }
         if (p.wino_d > 0) {  // Winograd input operand: 16 batches folded into grid.x (fastest), 96- or 64-row tiles
             if (cfg == 12) {
                 int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
@@ -1125,19 +1242,21 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
             }
             return;
         }
-        if (p.src2 != nullptr && p.zout != nullptr) {  // fused forward apply of the producing node (A operand + z)
-            NT_AFF_LAUNCH(2)
-            return;
+        // A operand: 2 = fused forward apply of the producing node (A operand + z), 3 = ... of a node without a residual
+        // branch, 1 = affine (fused BatchNorm-backward apply), 0 = plain
+        const int aff = (p.src2 != nullptr && p.zout != nullptr) ? 2 : (p.zout != nullptr ? 3 : (p.src2 != nullptr ? 1 : 0));
+        const bool ch = p.chunk_tiles > 0;
+        switch (aff * 2 + (ch ? 1 : 0)) {
+            case 0: launch_nt_pw<0, 0>(p, cfg, st); break;
+            case 1: launch_nt_pw<0, 1>(p, cfg, st); break;
+            case 2: launch_nt_pw<1, 0>(p, cfg, st); break;
+            case 3: launch_nt_pw<1, 1>(p, cfg, st); break;
+            case 4: launch_nt_pw<2, 0>(p, cfg, st); break;
+            case 5: launch_nt_pw<2, 1>(p, cfg, st); break;
+            case 6: launch_nt_pw<3, 0>(p, cfg, st); break;
+            default: launch_nt_pw<3, 1>(p, cfg, st); break;
         }
-        if (p.zout != nullptr) {  // ... of a node without a residual branch
-            NT_AFF_LAUNCH(3)
-            return;
-        }
-        if (p.src2 != nullptr) {  // affine A operand (fused BatchNorm-backward apply)
-            NT_AFF_LAUNCH(1)
-            return;
-        }
-#undef NT_AFF_LAUNCH
+        return;
     }
     if constexpr (MODE != 2) {
         static const int tap_inner = getenv("VSPW_TAP_INNER") ? atoi(getenv("VSPW_TAP_INNER")) : 1;
@@ -1160,31 +1279,27 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
             }
             return;
         }
-    }
-    if (cfg == 22) {
-        int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
-        // measured: short reductions (K <= 1024, i.e. the 1x1 convs) gain ~10 % from the higher residency of the
-        // single-buffer variant (3 workgroups/CU); long ones gain 2-5 % from the second buffer (one barrier per tile)
-        static const int nbuf1_max_k = getenv("VSPW_NBUF1_MAXK") ? atoi(getenv("VSPW_NBUF1_MAXK")) : 1024;
-        if (MODE == 2 && p.kdim <= nbuf1_max_k && launch_nt_persist<2, 2, 2, 0>(p, 128, 128, p.batch, st))
-            return;
-        if (p.kdim <= nbuf1_max_k)
-            hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
-        else
-            hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 2>), dim3(tiles, p.batch), dim3(256), 0, st, p);
-    } else if (cfg == 31) {
-        if (MODE == 2 && launch_nt_persist<1, 3, 1, 0>(p, 96, 128, p.batch, st)) return;
-        int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
-    } else if (cfg == 12) {
-        int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
-    } else if (cfg == 21) {
-        int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
-    } else {
-        int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
-        hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+        // other filter shapes (tap-outer K order)
+        if (cfg == 22) {
+            int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
+            static const int nbuf1_max_k = getenv("VSPW_NBUF1_MAXK") ? atoi(getenv("VSPW_NBUF1_MAXK")) : 1024;
+            if (p.kdim <= nbuf1_max_k)
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+            else
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 2>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+        } else if (cfg == 31) {
+            int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
+            hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+        } else if (cfg == 12) {
+            int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
+            hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+        } else if (cfg == 21) {
+            int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);
+            hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+        } else {
+            int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
+            hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, MODE, 1>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+        }
     }
 }
 
@@ -1215,6 +1330,8 @@ static int launch_igemm_nt(const IgemmNT& pin, hipStream_t st) {
     const int cfg = nt_decide(p, v2);
     if (v2) {
         const bool pw = p.kh * p.kw == 1 && p.stride == 1 && p.pad == 0 && p.padw == 0;
+        p.chunk_tiles = 0;
+        if (pw && p.wino_d == 0 && accum_chunk() >= BK && p.kdim >= 2 * accum_chunk()) p.chunk_tiles = accum_chunk() / BK;
         if (pw)
             launch_nt_v2<2>(p, cfg, st);  // forward and data gradient of a pointwise conv are the same plain GEMM
         else if (p.mode == 0)

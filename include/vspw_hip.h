@@ -29,7 +29,7 @@ extern "C" {
 #define VSPW_EINVAL (-1)  /* bad argument / geometry / workspace too small */
 #define VSPW_ELAUNCH (-2) /* hipLaunchKernel reported an error */
 
-#define VSPW_ABI_VERSION 5
+#define VSPW_ABI_VERSION 6
 int vspw_abi_version(void);
 /* The hipError_t behind the most recent VSPW_ELAUNCH (0 if none) - for error messages. */
 int vspw_last_hip_error(void);
@@ -122,6 +122,13 @@ typedef struct vspw_wt_entry {
 } vspw_wt_entry;
 long long vspw_weight_transpose_tiles(int k, int taps, int c);
 int vspw_weight_transpose_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream);
+/* Summation shape of the pointwise (1x1 / plain GEMM) kernels with a reduction of K >= 2*k terms: K/k chains of k terms,
+ * the finished chains parked in the output tile, instead of one k-sequential fp32 chain - the rounding error of a
+ * k-blocked CPU GEMM, which is what the reference's ATen conv2d / matmul (models/resnet.py:76-86, spatial_ocr_block.py:
+ * 252-274) runs on.  k: multiple of 32, default 256; 0 = one chain (the round 1-4 behaviour).  Process-wide policy,
+ * not per-call state: set it before issuing work. */
+int vspw_set_accum_chunk(int k);
+int vspw_get_accum_chunk(void);
 /* [n][c][hw] -> [n][hw][c]: the reference feeds NCHW images (train_clip2.py:45-47). */
 int vspw_nchw_to_nhwc(const float* in, float* out, int n, int c, long long hw, void* stream);
 

@@ -135,9 +135,62 @@ def test_winograd_path_equals_direct_path_in_a_fused_chain(dev, dil, h, w, wino_
         assert err < (2e-4 if nm in ("dbeta1", "dbeta2") else 2e-5), (nm, float(err))
 
 
+@pytest.mark.parametrize("n,c,h,w,k,bias", [
+    (4, 2048, 24, 32, 256, False),  # interior 96 / 128-row tiles, 8 chains of 256
+    (2, 1024, 12, 13, 200, True),   # ragged rows and columns: guarded flush, bias added once
+    (3, 512, 20, 20, 1024, False),  # two chains forward, four in the data gradient (K = output channels there)
+    (1, 4096, 40, 48, 512, False),  # K > 1024 on the 128x128 tile: two LDS buffers, flush scratch in the dead one
+])
+def test_pointwise_two_level_accumulation(dev, n, c, h, w, k, bias):
+    """K >= 2*chunk pointwise GEMMs sum K/chunk chains of chunk terms, the finished chains parked in the output tile
+    (igemm_nt_v2_body CHUNK, vspw_set_accum_chunk): same value as the single chain up to rounding, run-to-run
+    bit-identical, and CLOSER to the float64 result than the single k-sequential chain (the point of it: the
+    reference's k-blocked CPU GEMM has the smaller error - profiles/r05_parity_attrib.log)."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(5 + c + k)
+    x = torch.randn(n, c, h, w, generator=g)
+    wt = torch.randn(k, c, 1, 1, generator=g) * (2.0 / c) ** 0.5
+    b = torch.randn(k, generator=g) if bias else None
+    gy = torch.randn(n, k, h, w, generator=g)
+    xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, None if b is None else b.double())
+    ref.backward(gy.double())
+    ref, ref_dx = ref.detach(), xr.grad
+    out = {}
+    prev = ops.set_accum_chunk(256)
+    try:
+        for chunk in (0, 256, 256, 128):
+            ops.set_accum_chunk(chunk)
+            xd = x.to(dev).requires_grad_(True)
+            wd = wt.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            y = ops.conv2d(xd, wd, None if b is None else b.to(dev), 1, 0, 1)
+            y.backward(gy.to(dev))
+            ops.join_side_streams()
+            out.setdefault(chunk, []).append((y.detach().double().cpu(), xd.grad.double().cpu()))
+    finally:
+        ops.set_accum_chunk(prev)
+    for what, idx, want, kk in (("forward", 0, ref, c), ("data gradient", 1, ref_dx, k)):
+        rms = {c_: float((v[0][idx] - want).pow(2).mean().sqrt()) for c_, v in out.items()}
+        mx = {c_: float((v[0][idx] - want).abs().max()) for c_, v in out.items()}
+        print("%s K=%d: rms error single chain %.3e, chains of 256 %.3e, of 128 %.3e (max %.2e / %.2e / %.2e)"
+              % (what, kk, rms[0], rms[256], rms[128], mx[0], mx[256], mx[128]))
+        assert torch.equal(out[256][0][idx], out[256][1][idx]), what  # deterministic
+        scale = max(float(want.abs().max()), 1.0)
+        for c_ in mx:
+            assert mx[c_] <= 2e-6 * scale * max(kk / 256, 1.0) ** 0.5, (what, c_, mx[c_])
+        if kk >= 1024:
+            assert rms[256] < 0.8 * rms[0], (what, rms)   # the parked chains are measurably more accurate ...
+            assert rms[128] <= 1.05 * rms[256], (what, rms)  # ... and shorter ones no worse
+        elif kk < 512:
+            assert torch.equal(out[0][0][idx], out[256][0][idx]), what  # short reductions: one chain either way
+
+
 @pytest.mark.parametrize("n,c,h,w,k", [(2, 256, 16, 24, 64),   # interior 128x128 / 96-row tiles: accumulators seeded
                                        (1, 64, 9, 13, 32),     # ragged: every tile takes the guarded epilogue
-                                       (3, 1024, 20, 20, 256)])
+                                       (3, 1024, 20, 20, 256),  # forward K = 1024: four parked chains
+                                       (2, 256, 16, 24, 1024),  # data gradient K = 1024: parked chains + skip + BN front
+                                       (1, 128, 9, 13, 512)])   # ... on ragged tiles (guarded flush)
 def test_conv_bn_act_skip_gradient_is_folded_into_dgrad(dev, n, c, h, w, k):
     """Bottleneck entry (models/resnet.py:75-90): x feeds conv1 AND the skip.  With skip_out the skip gradient is added
     in conv1's data-gradient epilogue (vspw_conv2d_bwd_data_acc); the total must equal autograd's sum of both paths."""

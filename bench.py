@@ -55,7 +55,10 @@ def parse_args():
     ap.add_argument("--cpu-baseline-size", type=int, default=CROP,
                     help="crop of the CPU-baseline sample (B=2 clips x 1 frame); 479 = the workload's own frame size")
     ap.add_argument("--cpu-baseline-full", action="store_true",
-                    help="time ONE complete B=2, T=5 step of the oracle instead of 1 of the 5 frames x5 (minutes)")
+                    help="(the default since round 5; kept for old command lines)")
+    ap.add_argument("--cpu-baseline-one-frame", action="store_true",
+                    help="time 1 of the 5 frames of the oracle step and extrapolate x5 instead of ONE complete B=2, T=5 "
+                         "step (the default: ~3 min on a 64-thread host, ~60 GB of host memory)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-host-probe", action="store_true")
     ap.add_argument("--kernel-report", default="", help="write a per-shape GEMM efficiency table to this file "
@@ -136,12 +139,34 @@ def make_inputs(dev, seed, crop=CROP):
     return imgs, labs
 
 
+def host_mem_available_gb():
+    try:
+        with open("/proc/meminfo") as f:
+            for line in f:
+                if line.startswith("MemAvailable:"):
+                    gb = int(line.split()[1]) / 2 ** 20
+                    break
+            else:
+                return 0.0
+        for lim, use in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                         ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+            try:  # a container limit below what the host reports
+                lv = open(lim).read().strip()
+                if lv != "max" and int(lv) < 2 ** 60:
+                    gb = min(gb, (int(lv) - int(open(use).read().strip())) / 2 ** 30)
+            except Exception:
+                pass
+        return gb
+    except Exception:
+        return 0.0
+
+
 def cpu_baseline(S=CROP, full=False):
     """Numpy-oracle port timed on the host cores: TCB-PSP R101 forward+backward on B=2 clips x 1 of the 5 frames at
     SxS (default: the workload's own 479x479 frames, no pixel extrapolation).  The encoder / deep-supervision cost is
     linear in the number of frames, so one B=2, T=5 step ~ 5x this sample: clips/s = 2 / (5 t) (x (479/S)^2 if a
     smaller S was asked for); the x5 over-counts the pyramid head, which runs on the current frame only (4 % of the
-    step's FLOPs).  full=True times one complete T=5 step instead (--cpu-baseline-full; several minutes)."""
+    step's FLOPs).  full=True (bench.py's default) times one COMPLETE B=2, T=5 step instead: "extrapolated": false."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     from helpers import build, det_numpy_state
@@ -530,7 +555,11 @@ def main():
         if comm is not None:
             out["collectives"] = comm
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_size, full=args.cpu_baseline_full)
+            # one COMPLETE timed step of the oracle unless asked otherwise or the
+            # host cannot hold its ~60 GB of float32 activations (12 GB per frame pair, measured)
+            wd.phase("cpu baseline (one oracle step on the host cores)", 1500)
+            full = not args.cpu_baseline_one_frame and args.cpu_baseline_size == CROP and host_mem_available_gb() >= 96.0
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline_size, full=full)
     wd.phase("destroy process group")
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

@@ -37,7 +37,7 @@ _wino = {"enabled": os.environ.get("VSPW_WINOGRAD", "1") == "1", "min_c": int(os
 
 def set_accum_chunk(k):
     """Two-level accumulation of the pointwise GEMMs with K >= 2k (csrc/conv_igemm.hip, vspw_set_accum_chunk): k terms
-    per fp32 chain (multiple of 32; library default 256), 0 = one k-sequential chain.  Returns the previous setting."""
+    per fp32 chain (multiple of 32), 0 = one k-sequential chain (the library default).  Returns the previous setting."""
     prev = int(_C.query("vspw_get_accum_chunk"))
     _C.call("vspw_set_accum_chunk", int(k))
     return prev

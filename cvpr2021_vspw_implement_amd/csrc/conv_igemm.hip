@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT pin) {
 // One output tile.  vb_in = tile index of this workgroup (already XCD-remapped), batch_idx = batch of a batched GEMM,
 // stamp_slot = slot of the diagnostic stamps.  Called once per workgroup by igemm_nt_v2_kernel and in a loop by the
 // persistent variant below.
-template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS, int AFF, int CHUNK = 0>
+template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS, int AFF, int CHUNK = 0, int FOLD = 0>
 __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, int batch_idx, int stamp_slot) {
     IgemmNT p = pin;
     if (AFF != 4 && pin.batch > 1) {
@@ -390,6 +390,7 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
     static_assert(AFF != 4 || WM * WN <= 3, "Winograd operand: 4 staged float4 per row - the 96- / 64-row tiles only");
     static_assert(!CHUNK || (MODE == 2 && TAPS == 0 && AFF != 4), "two-level accumulation: plain pointwise K loop only");
     static_assert(!CHUNK || NBUF == 1 || 32 * WM * WGM >= 128, "flush scratch of 4 waves must fit ONE operand buffer");
+    static_assert(FOLD == 0 || (TAPS > 0 && TAPS % FOLD == 0 && WM * WN == 1), "folded chains: tap-inner loop, the 64x64 tile");
     // AFF 1: A = coef0*src + coef1*src2 + coef2 (BatchNorm-backward apply); AFF 2: A = relu(coef0*src + coef1 + src2);
     // AFF 3: A = relu(coef0*src + coef1) (no residual)
     // (BatchNorm-forward apply + residual + ReLU of the producing node), also stored to zout
@@ -706,29 +707,24 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
     (void)flush_partial;
     int chunk_left = chunked ? p.chunk_tiles : 0x7fffffff;
     bool flushed = false;
-#if defined(VSPW_NT_CHUNK) || defined(VSPW_NT_CHUNK_TAPS)
-    // DIAGNOSTIC build only (tools/diag/parity_attrib.sh): two-level accumulation - every VSPW_NT_CHUNK K-tiles the
-    // running sums are folded into a second accumulator set, the summation shape of a k-blocked CPU GEMM.  Answers
-    // "how much of |hip - ref64| is the k-sequential order of the MFMA chain"; never shipped (112-128 more registers).
-    f32x16 acc2[WM][WN];
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
-    auto flush_chunk = [&]() {
+    // ---- folded chains (FOLD, the direct 3x3 kernels) ----
+    // The 3x3 convolutions that do not go through Winograd - the stem, layer1, the strided ones: 64 / 128 channels, a
+    // 576- / 1152-term reduction at the START of the network, where a rounding error is amplified by every BatchNorm'd
+    // residual block that follows - carried the whole parity excess of the raw-weight fixtures
+    // (profiles/r05_parity_attrib_c_direct3x3.log: |hip - ref64| / |ref32 - ref64| 1.30-1.63 -> 0.80-1.02 with chains of
+    // 96 terms).  They run on the 64x64 tile (16 accumulators, see nt_folds), so here the second level is a second
+    // accumulator set in registers: every FOLD K-tiles (3 = one filter row of a 32-channel slab) acc2 += acc and the
+    // chain restarts.
+    f32x16 acc2[FOLD > 0 ? WM : 1][FOLD > 0 ? WN : 1];
+    if constexpr (FOLD > 0) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc2[i][j][r] += acc[i][j][r];
-                    acc[i][j][r] = 0.f;
-                }
-    };
-#endif
+                for (int r = 0; r < 16; ++r) acc2[i][j][r] = 0.f;
+    }
+    (void)acc2;
     NT_STAMP(1);
     NT_PRIO(0);
     if constexpr (TAPS > 0) {
@@ -782,9 +778,18 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
                     }
                 }
                 __syncthreads();
-#ifdef VSPW_NT_CHUNK_TAPS
-                if ((cs * TAPS + t + 1) % VSPW_NT_CHUNK_TAPS == 0) flush_chunk();  // (9 = one 32-channel slab = 288 k)
-#endif
+                if constexpr (FOLD > 0) {
+                    if ((t + 1) % FOLD == 0) {  // (compile-time: t is an unrolled index, TAPS % FOLD == 0)
+#pragma unroll
+                        for (int i = 0; i < WM; ++i)
+#pragma unroll
+                            for (int j = 0; j < WN; ++j) {
+                                acc2[i][j] += acc[i][j];
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                            }
+                    }
+                }
             }
         }
     } else {
@@ -860,22 +865,17 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
                 chunk_left = p.chunk_tiles;
             }
         }
-#ifdef VSPW_NT_CHUNK
-        if ((kt + 1) % VSPW_NT_CHUNK == 0) flush_chunk();
-#endif
     }
     }  // tap-outer order
     if constexpr (CHUNK) {
         if (flushed) p.addend = p.dst;  // the epilogue adds the parked partial sums (they already hold the caller's addend)
     }
-#if defined(VSPW_NT_CHUNK) || defined(VSPW_NT_CHUNK_TAPS)
+    if constexpr (FOLD > 0) {
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
-#endif
+            for (int j = 0; j < WN; ++j) acc[i][j] += acc2[i][j];
+    }
     NT_STAMP(2);
     NT_PRIO(NT_PRIO_EDGE);
 #ifdef VSPW_NT_DBG
@@ -1087,10 +1087,10 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
 #endif
 }
 
-template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, int AFF = 0, int CHUNK = 0>
+template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, int AFF = 0, int CHUNK = 0, int FOLD = 0>
 __global__ __launch_bounds__(256, NT_V2_BOUNDS(WM, WN, MODE, NBUF, TAPS, AFF)) void igemm_nt_v2_kernel(IgemmNT pin) {
-    igemm_nt_v2_body<WGM, WM, WN, MODE, NBUF, TAPS, AFF, CHUNK>(pin, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y,
-                                                                blockIdx.y * gridDim.x + blockIdx.x);
+    igemm_nt_v2_body<WGM, WM, WN, MODE, NBUF, TAPS, AFF, CHUNK, FOLD>(pin, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y,
+                                                                      blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // Persistent variant (short-K pointwise GEMMs): gridDim.x = resident workgroup slots (a multiple of 8), each workgroup
@@ -1181,11 +1181,32 @@ static bool launch_nt_persist(const IgemmNT& p, int tm, int tn, int fold, hipStr
     return true;
 }
 
+static int nt_tap_inner() {
+    static const int v = getenv("VSPW_TAP_INNER") ? atoi(getenv("VSPW_TAP_INNER")) : 1;
+    return v;
+}
+// Folded chains of the direct 3x3 kernels (igemm_nt_v2_body, FOLD): on unless VSPW_DIRECT_FOLD=0 (A/B runs,
+// tools/diag/parity_attrib.sh)
+static int nt_direct_fold() {
+    static const int v = getenv("VSPW_DIRECT_FOLD") ? atoi(getenv("VSPW_DIRECT_FOLD")) : 1;
+    return v;
+}
+// A direct (non-Winograd) 3x3 launch of the v2 kernel that folds its chains: the small-channel convolutions of the stem /
+// layer1 / the strided ones (c <= 128 - wider 3x3s reach the direct kernel only with Winograd switched off).  They run
+// on the 64x64 tile: 16 + 16 accumulators at four workgroups per CU, no spills - measured (tools/diag/direct3x3_time.py)
+// as fast as the unfolded 128x64 / 128x128 tiles on the stem (402 + 361 vs 388 + 358 us, 666 + 648 vs 625 + 635 us) and
+// FASTER on layer1 / layer2.0 (88 vs 97 us, 99 vs 113 us), where the larger tiles left CUs idle.
+static bool nt_folds(const IgemmNT& p) {
+    return p.kh == 3 && p.kw == 3 && p.c <= 128 && nt_tap_inner() && nt_direct_fold();
+}
+
 // Process-wide summation policy of the K >= 2*chunk pointwise GEMMs (see igemm_nt_v2_body, "two-level accumulation"):
-// chunk length in k (multiple of 32); 0 = one k-sequential chain.  Default 256, VSPW_ACCUM_CHUNK overrides it at load.
+// chunk length in k (multiple of 32); 0 = one k-sequential chain = the default (measured, profiles/r05_parity_attrib_*:
+// chains of 256 halve the rounding error of a K >= 1024 GEMM but move the end-to-end parity figures by < 0.1x while
+// costing 2.8 ms per step; the excess sat in the direct 3x3 kernels, see FOLD).  VSPW_ACCUM_CHUNK / vspw_set_accum_chunk.
 static int g_accum_chunk = -1;
 static int accum_chunk() {
-    if (g_accum_chunk < 0) g_accum_chunk = getenv("VSPW_ACCUM_CHUNK") ? atoi(getenv("VSPW_ACCUM_CHUNK")) / BK * BK : 256;
+    if (g_accum_chunk < 0) g_accum_chunk = getenv("VSPW_ACCUM_CHUNK") ? atoi(getenv("VSPW_ACCUM_CHUNK")) / BK * BK : 0;
     return g_accum_chunk;
 }
 extern "C" int vspw_set_accum_chunk(int k) {
@@ -1259,8 +1280,12 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
         return;
     }
     if constexpr (MODE != 2) {
-        static const int tap_inner = getenv("VSPW_TAP_INNER") ? atoi(getenv("VSPW_TAP_INNER")) : 1;
-        if (tap_inner && p.kh == 3 && p.kw == 3) {  // 3x3: channel-slab-outer / tap-inner K order
+        if (nt_tap_inner() && p.kh == 3 && p.kw == 3) {  // 3x3: channel-slab-outer / tap-inner K order
+            if (nt_folds(p)) {  // folded chains on the 64x64 tile (nt_decide has set cfg = 11)
+                int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, MODE, 1, 9, 0, 0, 3>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+                return;
+            }
             if (cfg == 22) {
                 int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
                 hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 1, 9>), dim3(tiles, p.batch), dim3(256), 0, st, p);
@@ -1321,6 +1346,7 @@ static int nt_decide(const IgemmNT& p, bool& v2) {
     v2 = p.vec && p.c % BK == 0 && span < (1LL << 28) && (long long)p.kdim < (1LL << 21) &&
          true;  // forward (any stride) and data gradient (any stride: inexact taps are masked per tap)
     if (!v2 && cfg == 31) cfg = 12;  // the generic kernel has no 96-row instantiation
+    if (v2 && nt_folds(p)) cfg = 11;  // direct 3x3 with folded chains: see nt_folds
     return cfg;
 }
 

@@ -125,8 +125,10 @@ int vspw_weight_transpose_multi(const vspw_wt_entry* entries, int n_entries, lon
 /* Summation shape of the pointwise (1x1 / plain GEMM) kernels with a reduction of K >= 2*k terms: K/k chains of k terms,
  * the finished chains parked in the output tile, instead of one k-sequential fp32 chain - the rounding error of a
  * k-blocked CPU GEMM, which is what the reference's ATen conv2d / matmul (models/resnet.py:76-86, spatial_ocr_block.py:
- * 252-274) runs on.  k: multiple of 32, default 256; 0 = one chain (the round 1-4 behaviour).  Process-wide policy,
- * not per-call state: set it before issuing work. */
+ * 252-274) runs on.  k: multiple of 32; 0 = one chain = the default (chains of 256 halve the error of a K >= 1024 GEMM
+ * but cost 3 % of the training step and move the end-to-end parity figures by < 0.1x: the excess over the reference's
+ * own fp32 noise sat in the direct 3x3 kernels, which fold their chains every 96 terms unconditionally - DESIGN.md
+ * section 4).  Process-wide policy, not per-call state: set it before issuing work. */
 int vspw_set_accum_chunk(int k);
 int vspw_get_accum_chunk(void);
 /* [n][c][hw] -> [n][hw][c]: the reference feeds NCHW images (train_clip2.py:45-47). */

@@ -10,7 +10,7 @@ Two weight variants per case (see make_golden_fullsize.py / det_init.damp_residu
           identical wherever the reference's top-2 log-probability gap exceeds 2e-3.
   raw     He-normal weights, gamma~U(0.5,1.5): 33 random BatchNorm'd residual blocks amplify float32 rounding ~1e4-fold;
           the reference's own fp32 logits are 1e-3..4e-3 from float64.  Both numbers are printed: the direct
-          |hip - ref32|, and |hip - ref64| held to max(1e-3, 2 x |ref32 - ref64|) (helpers.logit_tol's rule).
+          |hip - ref32|, and |hip - ref64| held to max(1e-3, RAW_GATE x |ref32 - ref64|), RAW_GATE = 1.5.
 """
 import numpy as np
 import pytest
@@ -21,7 +21,13 @@ from oracle.det_init import damp_residual_gammas, det_input, det_labels, det_sam
 
 pytestmark = pytest.mark.gpu
 H, W, S = 480, 853, 479
-RAW_GATE = 2.0  # raw-weight variant: |hip - ref64| <= max(1e-3, RAW_GATE x |ref32 - ref64|)
+# raw-weight variant: |hip - ref64| <= max(1e-3, RAW_GATE x |ref32 - ref64|).  Round 4 needed 2.0: HIP sat 1.3-1.6x farther
+# from float64 than the reference's own fp32.  Attributed in round 5 (profiles/r05_parity_attrib_*.log): not Winograd, not
+# the long pointwise reductions - the 576-term k-sequential chains of the direct 3x3 kernels in the stem / layer1, whose
+# error every later block amplifies.  With those chains folded every 96 terms (conv_igemm.hip FOLD) the measured ratio is
+# 0.80-1.20 on cfg 2/3/4, inference and training; the max over ~10^5 logits of one rounding realisation moves by +-0.2.
+RAW_GATE = 1.5
+RAW_FLIPS = 1.5  # arg-max disagreements with the reference's fp32 masks <= RAW_FLIPS x its own fp32-vs-fp64 count
 
 
 def _t(a, dev):
@@ -139,8 +145,11 @@ def test_480p_inference_against_reference_vectors(dev, kind, cfg, variant):
     assert ep <= 1e-3, ep
     assert np.abs(probs.sum(1) - 1).max() < 1e-5
     assert (flips & decisive).sum() == 0
+    own_flips = int((fx["argmax32"] != fx["argmax64"]).sum())
     if variant == "damped":  # no more disagreement with the reference's fp32 masks than 4x its own fp32-vs-fp64 count
-        assert flips.sum() <= 4 * max(int((fx["argmax32"] != fx["argmax64"]).sum()), 25), flips.sum()
+        assert flips.sum() <= 4 * max(own_flips, 25), flips.sum()
+    else:  # (two fp32 realisations differ ~1.4x more often from each other than either does from float64)
+        assert flips.sum() <= RAW_FLIPS * max(own_flips, 25), (flips.sum(), own_flips)
 
 
 @pytest.mark.parametrize("variant", ["damped", "raw"])

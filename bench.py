@@ -485,7 +485,8 @@ def main():
                 "allreduce_launch_to_done_ms_max": round(max([a.elapsed_time(b) for a, b in red_events.get("buckets", [])]
                                                             or [0.0]), 3),
                 "syncbn_exchange": ("peer exchange (hipIpc arenas, one kernel per exchange: csrc/exchange.hip)"
-                                    if getattr(model, "exchange", None) is not None else "torch.distributed all-reduce"),
+                                    if getattr(model, "exchange", None) is not None else
+                                    "torch.distributed all-reduce (peer exchange off: %s)" % getattr(model, "exchange_why", "?")),
                 "rccl_graph_capture": rccl_capture, "sync_bn": not args.no_sync_bn,
                 "sync_bn_formula": "clamp(var,eps)" if args.sync_bn_clamp_var else "var+eps"}
 
@@ -533,6 +534,7 @@ def main():
                        + ("" if args.crop == CROP else " - NOT the metric's 479x479 workload (--crop): plumbing only"),
                        "global_batch_clips": world * B_CLIPS, "frames_per_step_per_gpu": T_FRAMES * B_CLIPS,
                        "parallelism": "dp%d" % world, "sync_bn": collectives and not args.no_sync_bn,
+                       "ranks": world,
                        "rccl_ranks": 0 if SHARED_GPU_TEST else (
                            torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1),
                        "execution": "hipGraph replay" if graphed is not None else "eager launches",

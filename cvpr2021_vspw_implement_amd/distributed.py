@@ -268,17 +268,50 @@ class DataParallelOverRCCL(torch.nn.Module):
         self.reducer.broadcast_parameters(module)
         # SyncBN statistics: hipIpc peer exchange (peer_exchange.py) when every rank of the group could set it up and
         # its self-test passed everywhere, torch.distributed all-reduces otherwise (VSPW_SYNCBN_PEER=0: always)
+        self._sync_bn = bool(sync_bn)
+        self._batch_sig = None
         self.exchange = None
+        self.exchange_why = "not requested"  # why SyncBN statistics go through torch.distributed instead (bench.py reports it)
         if sync_bn and self.reducer.active and torch.cuda.is_available() and os.environ.get("VSPW_SYNCBN_PEER", "1") == "1":
             from .peer_exchange import PeerExchange
 
             xc = PeerExchange()
             self.exchange = xc if xc.ok else None
+            self.exchange_why = "" if xc.ok else (xc.why or "a peer could not set it up")
         ops.set_sync_bn(sync_bn and self.reducer.active, force=force_collectives, clamp_var=sync_bn_clamp_var,
                         exchange=self.exchange)
 
     def forward(self, *a, **k):
+        self._check_equal_batches(a, k)
         return self.module(*a, **k)
+
+    def _check_equal_batches(self, a, k):
+        """SyncBN totals are finalised with count = local rows x ranks (the fused exchange + finalise kernel carries
+        sums only), which is the reference's sum over the replicas' real sizes (models/sync_batchnorm/batchnorm.py:
+        110-131) only when every rank holds the same batch shape - what the drivers' drop_last guarantees.  A caller
+        that feeds uneven batches gets an error instead of silently biased statistics: the shapes are compared across
+        the ranks whenever the local signature changes (one small collective at the first step)."""
+        if not (self.training and self.reducer.active and self._sync_bn and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+
+        def shapes(o):
+            if torch.is_tensor(o):
+                return tuple(o.shape)
+            if isinstance(o, dict):
+                return tuple((kk, shapes(o[kk])) for kk in sorted(o, key=str) if torch.is_tensor(o[kk]) or isinstance(o[kk], (list, tuple, dict)))
+            if isinstance(o, (list, tuple)):
+                return tuple(shapes(v) for v in o)
+            return None
+
+        sig = (shapes(a), shapes(k))
+        if sig == self._batch_sig:
+            return
+        every = [None] * dist.get_world_size()
+        dist.all_gather_object(every, sig)
+        if any(e != every[0] for e in every):
+            raise ValueError("SyncBN over %d ranks needs the same batch shape on every rank (drop_last); got %r"
+                             % (len(every), every))
+        self._batch_sig = sig
 
     def finish_gradients(self):
         self.reducer.wait()

@@ -12,6 +12,7 @@ from .lr_groups import LrGroupsMixin
 from .models import nll_ignore_index
 from .ocr_modules.spatial_ocr_block import SpatialOCR_Module, SpatialTemporalGather_Module
 from .ocrnet import ocr_heads
+from ._metrics import pixel_accuracy
 
 
 class ClipOCRNet(LrGroupsMixin, nn.Module):
@@ -36,11 +37,7 @@ class ClipOCRNet(LrGroupsMixin, nn.Module):
         return [self.conv_3x3, self.spatial_context_head, self.spatial_ocr_head, self.head, self.dsn_head]
 
     def pixel_acc(self, pred, label):
-        _, preds = torch.max(pred, dim=1)
-        valid = (label >= 0).long()
-        acc_sum = torch.sum(valid * (preds == label).long())
-        pixel_sum = torch.sum(valid)
-        return acc_sum.float() / (pixel_sum.float() + 1e-10)
+        return pixel_accuracy(pred, label)
 
     def forward(self, feed_dict, segSize=None):
         c_img = feed_dict["img_data"]

@@ -13,6 +13,7 @@ from .. import nn as vnn
 from .. import ops
 from .lr_groups import LrGroupsMixin
 from .models import nll_ignore_index
+from ._metrics import pixel_accuracy
 
 BatchNorm2d = vnn.SynchronizedBatchNorm2d
 
@@ -75,11 +76,7 @@ class Clip_PSP(LrGroupsMixin, nn.Module):
         return roots
 
     def pixel_acc(self, pred, label):
-        _, preds = torch.max(pred, dim=1)
-        valid = (label >= 0).long()
-        acc_sum = torch.sum(valid * (preds == label).long())
-        pixel_sum = torch.sum(valid)
-        return acc_sum.float() / (pixel_sum.float() + 1e-10)
+        return pixel_accuracy(pred, label)
 
     def _temporal_weights(self, conv5, T):
         """softmax over the T frames of the pooled 1x1-conv score (clip_psp.py:147-152) -> [B, T]."""

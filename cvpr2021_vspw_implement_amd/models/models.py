@@ -13,6 +13,7 @@ import torch.nn as nn
 from .. import nn as vnn
 from .. import ops
 from . import resnet
+from ._metrics import pixel_accuracy
 
 BatchNorm2d = vnn.SynchronizedBatchNorm2d
 BN_MOMENTUM = 0.1
@@ -31,11 +32,7 @@ def nll_ignore_index(crit):
 class SegmentationModuleBase(nn.Module):
     def pixel_acc(self, pred, label):
         """reference models/models.py:65-71 (kept for API parity; the fused loss kernel returns the same number)."""
-        _, preds = torch.max(pred, dim=1)
-        valid = (label >= 0).long()
-        acc_sum = torch.sum(valid * (preds == label).long())
-        pixel_sum = torch.sum(valid)
-        return acc_sum.float() / (pixel_sum.float() + 1e-10)
+        return pixel_accuracy(pred, label)
 
 
 class SegmentationModule(SegmentationModuleBase):

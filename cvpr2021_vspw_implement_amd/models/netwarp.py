@@ -13,6 +13,7 @@ from .. import nn as vnn
 from .. import ops
 from .lr_groups import LrGroupsMixin
 from .models import conv3x3_bn_relu, nll_ignore_index
+from ._metrics import pixel_accuracy
 
 BatchNorm2d = vnn.SynchronizedBatchNorm2d
 
@@ -56,10 +57,11 @@ def _load_flow_net(args):
 def _pad_to_8(x):
     """RAFT's InputPadder('sintel') (RAFT_core/utils/utils.py:7-25): zero-pad H,W up to multiples of 8 (the
     reference's replicate mode is commented out, utils.py:19-20: mode='constant')."""
+    from ..RAFT_core.utils.utils import margins_to_multiple_of_8
+
     h, w = x.shape[-2:]
-    ph, pw = (((h // 8) + 1) * 8 - h) % 8, (((w // 8) + 1) * 8 - w) % 8
-    pad = [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2]
-    return ops.plane_shift(x, (h + ph, w + pw), pad[2], pad[0]), pad
+    top, bottom, left, right = margins_to_multiple_of_8(h, w)
+    return ops.plane_shift(x, (h + top + bottom, w + left + right), top, left), [left, right, top, bottom]
 
 
 class _NetWarpBase(LrGroupsMixin, nn.Module):
@@ -92,11 +94,7 @@ class _NetWarpBase(LrGroupsMixin, nn.Module):
             yield w
 
     def pixel_acc(self, pred, label):
-        _, preds = torch.max(pred, dim=1)
-        valid = (label >= 0).long()
-        acc_sum = torch.sum(valid * (preds == label).long())
-        pixel_sum = torch.sum(valid)
-        return acc_sum.float() / (pixel_sum.float() + 1e-10)
+        return pixel_accuracy(pred, label)
 
     def _flow(self, cur255, prev255):
         with torch.no_grad():

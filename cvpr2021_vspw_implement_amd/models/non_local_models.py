@@ -9,6 +9,7 @@ from .. import ops
 from .lr_groups import LrGroupsMixin
 from .models import nll_ignore_index
 from .non_local import NLBlockND
+from ._metrics import pixel_accuracy
 
 
 class Non_local3d(LrGroupsMixin, nn.Module):
@@ -25,11 +26,7 @@ class Non_local3d(LrGroupsMixin, nn.Module):
         return [self.emb, self.nonlocalblock, self.last_layer]
 
     def pixel_acc(self, pred, label):
-        _, preds = torch.max(pred, dim=1)
-        valid = (label >= 0).long()
-        acc_sum = torch.sum(valid * (preds == label).long())
-        pixel_sum = torch.sum(valid)
-        return acc_sum.float() / (pixel_sum.float() + 1e-10)
+        return pixel_accuracy(pred, label)
 
     def forward(self, feed_dict, segSize=None):
         clip_imgs = feed_dict["clipimgs_data"]

@@ -110,6 +110,9 @@ class PeerExchange:
         """48 exchanges of rank-dependent patterns (lengths 1 ... SLOT_DOUBLES): totals must be exact on every rank."""
         try:
             w = self.world
+            # test hook (tests/test_bench_gpu.py): this rank reports a failed self-test - EVERY rank must then fall back
+            if os.environ.get("VSPW_PEER_SELFTEST_FAIL_RANK") == str(self.rank):
+                self.why = "self-test: failure injected on rank %d (VSPW_PEER_SELFTEST_FAIL_RANK)" % self.rank
             for k in range(48):
                 n = [1, 2, 130, 1024, 4096, self.SLOT_DOUBLES][k % 6]
                 base = torch.arange(n, dtype=torch.float64, device=self.dev) * 0.5 + k
@@ -122,7 +125,7 @@ class PeerExchange:
             if int(self.status.item()) != 0:
                 self.why = "self-test: a wait timed out"
                 return False
-            return True
+            return not self.why.startswith("self-test: failure injected")  # (the rounds above still ran: peers wait in them)
         except Exception as e:  # noqa: BLE001
             self.why = "self-test raised %r" % (e,)
             return False

@@ -62,6 +62,60 @@ def test_bench_launches_two_ranks_and_reports_once(dev):
     assert "[rank 0" in r.stderr and "[rank 1" in r.stderr  # the phase log of both ranks
 
 
+@pytest.mark.parametrize("method", ["clip_psp", "clip_ocr"])
+def test_bench_eight_ranks_plumbing(dev, method):
+    """The launch the driver's SCALE run will make - `bench.py --gpus 8` - with the eight ranks sharing this box's one
+    GPU (test mode: gloo instead of RCCL, which refuses two ranks per device; `rccl_ranks` is therefore 0 here and 8 on
+    an 8-GPU node) at 95x95 crops: parameter broadcast, 8-way peer statistics exchange per BatchNorm, bucketed
+    gradient averaging, barrier + max-over-ranks timing, exactly ONE JSON line.  cfg 4 (TCB-OCR) is the configuration
+    BASELINE.json names for 8 GPUs."""
+    import time
+
+    env = dict(os.environ, VSPW_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", VSPW_DIST_TIMEOUT_S="90",
+               VSPW_WATCHDOG_S="100")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--crop", "95",
+           "--method", method, "--no-cpu-baseline", "--no-host-probe", "--no-kernel-timing"]
+    t0 = time.time()
+    rc, out, err = _run(cmd, env, 200)
+    wall = time.time() - t0
+    assert rc == 0, err[-4000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    o = json.loads(lines[0])
+    print("8 ranks on one GPU, %s at 95x95: %.0f s wall, %.1f ms/step, collectives %s" % (method, wall, o["ms_per_step"],
+                                                                                         json.dumps(o["collectives"])))
+    assert o["n_gpus"] == 8 and o["config"]["ranks"] == 8 and o["config"]["parallelism"] == "dp8"
+    assert o["config"]["global_batch_clips"] == 16 and o["scaling"] == "weak"
+    assert abs(o["value"] - 8 * 2 / (o["ms_per_step"] / 1e3)) < 0.05 * o["value"]
+    c = o["collectives"]
+    assert c["syncbn_exchanges_per_step"] > 200 and "peer exchange" in c["syncbn_exchange"] and c["grad_buckets"] >= 4
+    assert 6.0 < o["last_loss"] < 8.0
+    for r in range(8):
+        assert "[rank %d" % r in err
+    assert wall < 120.0, wall  # (a fresh box: ~20 s of that is eight concurrent `import torch`)
+
+
+def test_peer_exchange_failure_on_one_rank_makes_every_rank_fall_back(dev):
+    """Start-up of the hipIpc statistics exchange is collective: a self-test that fails on ONE rank
+    (VSPW_PEER_SELFTEST_FAIL_RANK, a hook in peer_exchange._self_test) must switch EVERY rank to the torch.distributed
+    path - a mixed group would pair an all-reduce with a peer kernel and hang.  The run completes and says so."""
+    env = dict(os.environ, VSPW_BENCH_SHARED_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", VSPW_DIST_TIMEOUT_S="90",
+               VSPW_WATCHDOG_S="100", VSPW_PEER_SELFTEST_FAIL_RANK="1")
+    env.pop("WORLD_SIZE", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--crop", "95",
+           "--no-cpu-baseline", "--no-host-probe", "--no-kernel-timing"]
+    rc, out, err = _run(cmd, env, 200)
+    assert rc == 0, err[-4000:]
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    o = json.loads(lines[0])
+    c = o["collectives"]
+    assert c["syncbn_exchange"].startswith("torch.distributed all-reduce"), c["syncbn_exchange"]
+    assert "peer statistics exchange disabled" in err
+    assert c["syncbn_exchanges_per_step"] > 200 and 6.0 < o["last_loss"] < 8.0
+
+
 def test_bench_refuses_more_ranks_than_devices(dev):
     import torch
 

@@ -290,7 +290,8 @@ def _errors(get, ref, names, scale):
 # measured on the MI355X box (r05): per-parameter relative L2 of the HIP gradients against the float64 oracle on the SAME
 # piecewise-linear branch - see the print of the test; the gates sit at ~2x those figures, a factor 10 below what the
 # free comparison shows (3e-2 ... 7e-2), so a smooth error in ONE backward kernel cannot hide behind ReLU flips
-PINNED_GATE = {"median": 2.5e-3, "p99": 6e-3, "max": 8e-3}
+# (r05, MI355X: median 3.91e-04, p99 4.68e-04, max 8.66e-04 at ppm_conv.ppm.0.0.weight; float64 oracle job 28 s)
+PINNED_GATE = {"median": 8e-4, "p99": 1.0e-3, "max": 2e-3}
 
 
 def test_pinned_decision_gradients_one_head_default_suite(dev, tmp_path):

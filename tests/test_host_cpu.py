@@ -89,9 +89,11 @@ def test_netwarp_builds_the_hip_raft_with_reference_keys():
     assert all(not p.requires_grad for p in mod.raft.parameters())
     assert not any(k.startswith("raft.") for k, p in mod.named_parameters() if p.requires_grad)
     pad = InputPadder((479, 853))
-    x = pad.pad(torch.ones(1, 3, 479, 853))
-    assert x.shape[-2:] == (480, 856) and float(x[0, 0, -1, 0]) == 0.0  # zeros, not replicate
-    assert pad.unpad(x).shape[-2:] == (479, 853)
+    assert pad.padded_size == (480, 856) and pad._pad == [1, 2, 0, 1]  # (left, right, top, bottom), 'sintel' split
+    assert InputPadder((131, 150))._pad == [1, 1, 2, 3] and InputPadder((131, 150), mode="kitti")._pad == [1, 1, 0, 5]
+    assert InputPadder((480, 856))._pad == [0, 0, 0, 0]
+    with pytest.raises(RuntimeError):  # a HIP gather (values: tests/test_ops_gpu.py::test_flow_plumbing_gathers...)
+        pad.pad(torch.ones(1, 3, 479, 853))
     with pytest.raises(RuntimeError):  # no CPU fallback
         mod.raft(torch.zeros(1, 3, 128, 128), torch.zeros(1, 3, 128, 128), iters=1, test_mode=True)
 
@@ -153,7 +155,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_C.LIB_PATH)
     missing = [n for n in decls if not hasattr(lib, n)]
     assert not missing, missing
-    assert _C.load(check_symbols=True).vspw_abi_version() == 5
+    assert _C.load(check_symbols=True).vspw_abi_version() == 6
     # workspace queries are pure host functions: exercise the ABI without a GPU
     d = _C.ConvDesc(10, 60, 60, 256, 60, 60, 256, 3, 3, 1, 2, 2, 2)
     assert _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d)) > 0

@@ -827,6 +827,14 @@ def test_flow_plumbing_gathers_match_aten(dev, hw, out):
     assert torch.equal(padded.cpu(), F.pad(img, pad, mode="constant"))
     back = ops.plane_shift(padded, (h, w), -pad[2], -pad[0])
     assert torch.equal(back.cpu(), img)
+    from cvpr2021_vspw_implement_amd.RAFT_core.utils.utils import InputPadder
+
+    for mode in ("sintel", "kitti"):  # the import-surface mirror of the reference's class, on the same gather
+        ip = InputPadder(img.shape, mode)
+        ref_pad = [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2] if mode == "sintel" else [pw // 2, pw - pw // 2, 0, ph]
+        assert ip._pad == ref_pad
+        pp = ip.pad(img.to(dev))
+        assert torch.equal(pp.cpu(), F.pad(img, ref_pad, mode="constant")) and torch.equal(ip.unpad(pp).cpu(), img)
     mean, std = torch.FloatTensor([0.485, 0.456, 0.406]), torch.FloatTensor([0.229, 0.224, 0.225])
     un = ops.unnormalize_rgb(img.to(dev), std.tolist(), mean.tolist(), 255.0)
     assert torch.equal(un.cpu(), (img * std.view(1, 3, 1, 1) + mean.view(1, 3, 1, 1)) * 255.0)

@@ -75,7 +75,7 @@ def test_bench_eight_ranks_plumbing(dev, method):
                VSPW_WATCHDOG_S="100")
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--crop", "95",
-           "--method", method, "--no-cpu-baseline", "--no-host-probe", "--no-kernel-timing"]
+           "--method", method, "--no-cpu-baseline", "--no-host-probe"]  # (kernel timing on: `collectives` needs it)
     t0 = time.time()
     rc, out, err = _run(cmd, env, 200)
     wall = time.time() - t0
@@ -104,7 +104,7 @@ def test_peer_exchange_failure_on_one_rank_makes_every_rank_fall_back(dev):
                VSPW_WATCHDOG_S="100", VSPW_PEER_SELFTEST_FAIL_RANK="1")
     env.pop("WORLD_SIZE", None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--crop", "95",
-           "--no-cpu-baseline", "--no-host-probe", "--no-kernel-timing"]
+           "--no-cpu-baseline", "--no-host-probe"]
     rc, out, err = _run(cmd, env, 200)
     assert rc == 0, err[-4000:]
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]

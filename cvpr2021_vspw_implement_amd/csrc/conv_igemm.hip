@@ -30,11 +30,20 @@
 #ifdef VSPW_NT_TIMING
 // DIAGNOSTIC build (-DVSPW_NT_TIMING): per-workgroup s_memtime stamps [start, after prologue, after K loop, end] + CU id
 // (-DVSPW_NT_TIMING=2: slot 1 is overwritten with "every store of the tile issued"); read by tools/diag/nt_phase.py
+// (-DVSPW_NT_TIMING=3: the stamps are the 100 MHz wall clock instead - the same on every XCD, so a launch's first start and
+// last end can be compared with the kernel's duration as rocprofv3 / HIP events see it; tools/diag/nt_balance.py)
 __device__ unsigned long long vspw_nt_stamps[8192 * 5];
-#define NT_STAMP(i) if (threadIdx.x == 0 && stamp_slot < 8192) vspw_nt_stamps[stamp_slot * 5 + (i)] = __builtin_readcyclecounter()
+#if VSPW_NT_TIMING == 3
+#define NT_CLOCK(i) wall_clock64()
+#elif VSPW_NT_TIMING == 4  // calibration: slots 0 / 3 = s_memtime, slots 1 / 2 = wall clock at (nearly) the same moments
+#define NT_CLOCK(i) (((i) == 1 || (i) == 2) ? wall_clock64() : __builtin_readcyclecounter())
+#else
+#define NT_CLOCK(i) __builtin_readcyclecounter()
+#endif
+#define NT_STAMP(i) if (threadIdx.x == 0 && stamp_slot < 8192) vspw_nt_stamps[stamp_slot * 5 + (i)] = NT_CLOCK(i)
 #define TN_STAMP(i)                                                                       \
     if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 8192)                   \
-    vspw_nt_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 5 + (i)] = __builtin_readcyclecounter()
+    vspw_nt_stamps[(blockIdx.y * gridDim.x + blockIdx.x) * 5 + (i)] = NT_CLOCK(i)
 #else
 #define NT_STAMP(i)
 #define TN_STAMP(i)
@@ -369,6 +378,22 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT pin) {
 #define NT_PRIO_EDGE 2
 #endif
 #define NT_PRIO(x) __builtin_amdgcn_s_setprio(x)
+// Progress-dependent wave priority inside the K loop (experiment, -DVSPW_PROGRESS_PRIO): the SIMD arbitrates equal
+// priorities oldest-first, so the three co-resident workgroups of a single-round launch finish one after the other
+// (stamps, tools/diag/nt_balance.py: lives of 150 k / 230 k / 325 k cycles on one CU) and the last one runs alone, one
+// wave per SIMD, for the final third of the launch.  Priority falling with progress lets the laggards catch up.
+#ifdef VSPW_PROGRESS_PRIO
+#define NT_PROGRESS_PRIO(kt, nk)                                              \
+    do {                                                                      \
+        const int q_ = (nk) >> 2;                                             \
+        if ((kt) == 0) NT_PRIO(3);                                            \
+        else if ((kt) == q_) NT_PRIO(2);                                      \
+        else if ((kt) == 2 * q_) NT_PRIO(1);                                  \
+        else if ((kt) == 3 * q_) NT_PRIO(0);                                  \
+    } while (0)
+#else
+#define NT_PROGRESS_PRIO(kt, nk)
+#endif
 
 #define NT_V2_BOUNDS(WM, WN, MODE, NBUF, TAPS, AFF) \
     ((WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAPS == 0) ? 4 : ((NBUF == 1 && !(AFF && WM * WN > 3)) ? 3 : 2))
@@ -808,6 +833,7 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
     }
 
     for (int kt = 0; kt < nk; ++kt) {
+        NT_PROGRESS_PRIO(kt, nk);
         const int cur = (NBUF == 2) ? (kt & 1) : 0;
         if (NBUF == 1) {
             store_tile(As[0], Bs[0]);  // tile kt (loaded during iteration kt-1)
@@ -1087,10 +1113,41 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
 #endif
 }
 
+// Sustained shader clock under the real load (bench.py's `roofline.sustained_clock_ghz`): workgroup 0 of every v2 NT launch
+// reads s_memtime (shader cycles) and the 100 MHz wall clock when it starts and when it ends and adds both differences to
+// two device counters - four scalar reads and two atomics per LAUNCH.  Why it is worth having: the chip clocks to its power
+// budget, and fp32 MFMA on real (random-mantissa) operands is what it budgets hardest - measured on the 36 000 x 256 x 1024
+// GEMM (tools/diag/nt_clock.py, profiles/r05_nt_clock.log): 1.93 GHz and 110.5 TFLOP/s on random operands, 2.34 GHz and
+// 131.1 TFLOP/s on the SAME launch with zero-filled operands.  The 157.3 TFLOP/s peak is quoted at 2.4 GHz.
+__device__ unsigned long long vspw_nt_clock_probe[4];  // [0] ticks start, [1] wall start (scratch); [2] sum ticks, [3] sum wall
 template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, int AFF = 0, int CHUNK = 0, int FOLD = 0>
 __global__ __launch_bounds__(256, NT_V2_BOUNDS(WM, WN, MODE, NBUF, TAPS, AFF)) void igemm_nt_v2_kernel(IgemmNT pin) {
+    const bool probe = (blockIdx.x | blockIdx.y | threadIdx.x) == 0;
+    if (probe) {
+        vspw_nt_clock_probe[0] = __builtin_readcyclecounter();
+        vspw_nt_clock_probe[1] = wall_clock64();
+    }
     igemm_nt_v2_body<WGM, WM, WN, MODE, NBUF, TAPS, AFF, CHUNK, FOLD>(pin, xcd_remap(blockIdx.x, gridDim.x), blockIdx.y,
                                                                       blockIdx.y * gridDim.x + blockIdx.x);
+    if (probe) {
+        const unsigned long long t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+        atomicAdd(&vspw_nt_clock_probe[2], t1 - vspw_nt_clock_probe[0]);
+        atomicAdd(&vspw_nt_clock_probe[3], w1 - vspw_nt_clock_probe[1]);
+    }
+}
+
+// out[0] = shader cycles, out[1] = 100 MHz wall ticks accumulated by the probe above since the last reset (synchronises the
+// device: diagnostics / bench.py only); reset != 0 zeroes the sums afterwards.
+extern "C" int vspw_debug_nt_clock(unsigned long long* out, int reset) {
+    unsigned long long h[4];
+    if (hipDeviceSynchronize() != hipSuccess) return VSPW_ELAUNCH;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(vspw_nt_clock_probe), sizeof(h)) != hipSuccess) return VSPW_ELAUNCH;
+    if (out) { out[0] = h[2]; out[1] = h[3]; }
+    if (reset) {
+        h[2] = h[3] = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(vspw_nt_clock_probe), h, sizeof(h)) != hipSuccess) return VSPW_ELAUNCH;
+    }
+    return VSPW_OK;
 }
 
 // Persistent variant (short-K pointwise GEMMs): gridDim.x = resident workgroup slots (a multiple of 8), each workgroup
@@ -1826,6 +1883,7 @@ __global__ __launch_bounds__(256) void igemm_tn_v2_kernel(IgemmTN pin) {
     TN_STAMP(1);
     NT_PRIO(0);
     for (int kt = 0; kt < nk; ++kt) {
+        NT_PROGRESS_PRIO(kt, nk);
         const int cur = (NBUF == 2) ? (kt & 1) : 0;
         if (NBUF == 1) {
             store_tile(As[0], Bs[0]);

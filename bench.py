@@ -456,10 +456,10 @@ def main():
                         # count): can exceed 1 because Winograd executes 4/9 of the 3x3 multiplications
                         "frac_effective": round(effective / FP32_MFMA_PEAK_TFLOPS, 4)}
             if sustained_ghz:
-                # the chip clocks to its power budget: on real operands the fp32 MFMA loop runs at 1.9-2.0 GHz, not at
-                # the 2.4 GHz of the quoted peak (same launch, zero-filled operands: 2.34 GHz and +19 % TFLOP/s -
-                # profiles/r05_nt_clock.log).  `frac` above stays against the quoted peak; this is the same figure
-                # against what the matrix pipe can deliver at the clock it was actually given.
+                # a GEMM launch costs a constant number of cycles; the clock it is given varies with operand values and
+                # recent load (1.87 ... 2.40 GHz measured on one shape, profiles/r05_nt_clock.log).  `frac` above stays
+                # against the peak quoted at 2.4 GHz; this is the same figure against what the matrix pipe can deliver
+                # at the clock these launches actually ran at = the share of their cycles that carry an MFMA.
                 at_clock = FP32_MFMA_PEAK_TFLOPS * sustained_ghz / PEAK_CLOCK_GHZ
                 roofline.update({"sustained_clock_ghz": round(sustained_ghz, 3),
                                  "peak_at_sustained_clock": round(at_clock, 1),

@@ -1115,10 +1115,11 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
 
 // Sustained shader clock under the real load (bench.py's `roofline.sustained_clock_ghz`): workgroup 0 of every v2 NT launch
 // reads s_memtime (shader cycles) and the 100 MHz wall clock when it starts and when it ends and adds both differences to
-// two device counters - four scalar reads and two atomics per LAUNCH.  Why it is worth having: the chip clocks to its power
-// budget, and fp32 MFMA on real (random-mantissa) operands is what it budgets hardest - measured on the 36 000 x 256 x 1024
-// GEMM (tools/diag/nt_clock.py, profiles/r05_nt_clock.log): 1.93 GHz and 110.5 TFLOP/s on random operands, 2.34 GHz and
-// 131.1 TFLOP/s on the SAME launch with zero-filled operands.  The 157.3 TFLOP/s peak is quoted at 2.4 GHz.
+// two device counters - four scalar reads and two atomics per LAUNCH.  Why it is worth having: a launch costs a constant
+// number of CYCLES, and the clock it gets is the power management's decision - measured on the 36 000 x 256 x 1024 GEMM
+// (tools/diag/nt_clock{,_idle}.py, profiles/r05_nt_clock.log): 329-354 k cycles every time, at 1.87 ... 2.40 GHz depending on
+// operand values (zero-filled: 2.34 GHz, random: 1.9) and on what ran in the milliseconds before = 109 ... 131 TFLOP/s from
+// the same code.  The 157.3 TFLOP/s peak is quoted at 2.4 GHz.
 __device__ unsigned long long vspw_nt_clock_probe[4];  // [0] ticks start, [1] wall start (scratch); [2] sum ticks, [3] sum wall
 template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, int AFF = 0, int CHUNK = 0, int FOLD = 0>
 __global__ __launch_bounds__(256, NT_V2_BOUNDS(WM, WN, MODE, NBUF, TAPS, AFF)) void igemm_nt_v2_kernel(IgemmNT pin) {

@@ -133,8 +133,9 @@ int vspw_set_accum_chunk(int k);
 int vspw_get_accum_chunk(void);
 /* Diagnostics: shader cycles (out[0]) and 100 MHz wall-clock ticks (out[1]) that workgroup 0 of every forward / data-
  * gradient GEMM launch spent between its first and last instruction since the last reset - their ratio x 0.1 is the shader
- * clock in GHz the chip sustained under that load (it clocks to its power budget: 1.9-2.0 GHz on real operands against the
- * 2.4 GHz the 157.3 TFLOP/s fp32 MFMA peak is quoted at; bench.py reports it as roofline.sustained_clock_ghz).
+ * clock in GHz the chip sustained under that load (measured 1.87 ... 2.40 GHz on the same GEMM depending on operand values
+ * and on the preceding milliseconds; the 157.3 TFLOP/s fp32 MFMA peak is quoted at 2.4 GHz; bench.py reports it as
+ * roofline.sustained_clock_ghz).
  * Synchronises the device.  reset != 0: zero the sums afterwards. */
 int vspw_debug_nt_clock(unsigned long long* out, int reset);
 /* [n][c][hw] -> [n][hw][c]: the reference feeds NCHW images (train_clip2.py:45-47). */

@@ -247,6 +247,85 @@ __global__ __launch_bounds__(64) void convex_upsample_kernel(const float* __rest
     out[o + (size_t)H * W] = uy;
 }
 
+// ------------------------------------------------------------------------------------------------ thin convolutions
+// FlowHead.conv2 (3x3, 256 -> 2 channels, update.py:13-14) is a GEMM in name only: it fills 2 of the 64 columns of an MFMA
+// tile (round 5: 54 us per iteration through the implicit GEMM, 20 iterations per forward).  Direct form for few outputs
+// (k <= 4; stride 1, undilated, zero padding): one WAVE per output pixel, lane = 4 input channels (+256 per pass), the
+// k x taps weight quads of the lane live in registers across the pixels a wave walks; wave_sum per output channel: 22.6 us.
+// (The mirror case - BasicMotionEncoder.convf1, 7x7 on the 2 flow channels -> 128 - was tried as a direct kernel with the
+// filter bank in LDS too: 73 us against the implicit GEMM's 22; it stays a GEMM.  tools/diag/thin_time.py)
+__device__ __forceinline__ float thin_act(float v, int act) {
+    if (act == 1) return fmaxf(v, 0.f);
+    if (act == 2) return 1.f / (1.f + expf(-v));
+    if (act == 3) return tanhf(v);
+    return v;
+}
+
+template <int KOUT, int TAPS_MAX>
+__global__ __launch_bounds__(256) void conv_few_outputs_kernel(const float* __restrict__ x, long long ldx,
+                                                               const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ y, long long ldy, int n, int h, int wd,
+                                                               int c, int kh, int kw, int ph, int pw, int act,
+                                                               int pixels_per_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long P = (long long)n * h * wd;
+    const int taps = kh * kw;
+    const int c4 = lane * 4;
+    // (c <= 256 per pass; wider inputs take further passes over the channel range)
+    for (int cb = 0; cb < c; cb += 256) {
+        const bool cok = cb + c4 < c;
+        f32x4 wr[KOUT][TAPS_MAX];
+#pragma unroll
+        for (int k = 0; k < KOUT; ++k)
+#pragma unroll
+            for (int t = 0; t < TAPS_MAX; ++t) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                wr[k][t] = (cok && t < taps) ? *reinterpret_cast<const f32x4*>(w + ((size_t)k * taps + t) * c + cb + c4) : z;
+            }
+        const long long p0 = ((long long)blockIdx.x * 4 + wave) * pixels_per_wave;
+        for (int i = 0; i < pixels_per_wave; ++i) {
+            const long long pix = p0 + i;
+            if (pix >= P) break;  // (wave-uniform)
+            const int img = (int)(pix / ((long long)h * wd));
+            const int r = (int)(pix - (long long)img * h * wd);
+            const int oy = r / wd, ox = r - oy * wd;
+            float acc[KOUT];
+#pragma unroll
+            for (int k = 0; k < KOUT; ++k) acc[k] = 0.f;
+#pragma unroll
+            for (int t = 0; t < TAPS_MAX; ++t) {
+                const int ky = t / kw, kx = t - ky * kw;
+                const int sy = oy - ph + ky, sx = ox - pw + kx;  // (wave-uniform)
+                if (t < taps && (unsigned)sy < (unsigned)h && (unsigned)sx < (unsigned)wd && cok) {
+                    const f32x4 xv =
+                        *reinterpret_cast<const f32x4*>(x + (((size_t)img * h + sy) * wd + sx) * ldx + cb + c4);
+#pragma unroll
+                    for (int k = 0; k < KOUT; ++k) {
+                        const f32x4 pr = xv * wr[k][t];
+                        acc[k] += (pr[0] + pr[1]) + (pr[2] + pr[3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KOUT; ++k) acc[k] = wave_sum(acc[k]);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < KOUT; ++k) {
+                    float* o = y + (size_t)pix * ldy + k;
+                    if (c <= 256)
+                        *o = thin_act(acc[k] + (bias ? bias[k] : 0.f), act);
+                    else if (cb == 0)
+                        *o = acc[k];  // partial: later passes add, the last one finishes
+                    else if (cb + 256 < c)
+                        *o += acc[k];
+                    else
+                        *o = thin_act(*o + acc[k] + (bias ? bias[k] : 0.f), act);
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------- C ABI
 extern "C" size_t vspw_instance_norm_workspace(int n, int hw, int c) {
     if (n <= 0 || hw <= 0 || c <= 0) return 0;
@@ -328,5 +407,34 @@ extern "C" int vspw_convex_upsample(const float* flow, long long ldf, const floa
     if (rows > 0x7fffffffLL) return VSPW_EINVAL;
     hipLaunchKernelGGL(convex_upsample_kernel, dim3((unsigned)rows), dim3(64), 0, vspw_stream(stream), flow, (int)ldf,
                        mask, (int)ldm, mask_scale, out, h, w);
+    return vspw_launch_status();
+}
+
+// 1 when vspw_conv2d_thin runs this convolution (stride 1, undilated; see the kernels above)
+extern "C" int vspw_conv2d_thin_supported(const vspw_conv_desc* d, long long ldx, long long ldy) {
+    if (!d || d->stride != 1 || d->dil != 1 || d->oh != d->h + 2 * d->pad - d->kh + 1 ||
+        d->ow != d->w + 2 * d->pad_w - d->kw + 1 || d->oh != d->h || d->ow != d->w)
+        return 0;
+    const int taps = d->kh * d->kw;
+    if (d->k <= 4 && d->c % 4 == 0 && d->c >= 64 && taps <= 9 && ldx % 4 == 0) return 1;
+    (void)ldy;
+    return 0;
+}
+
+extern "C" int vspw_conv2d_thin(const vspw_conv_desc* d, const float* x, long long ldx, const float* w, const float* bias,
+                                int act, float* y, long long ldy, void* stream) {
+    const int kind = vspw_conv2d_thin_supported(d, ldx, ldy);
+    if (!kind || !x || !w || !y || ldx < d->c || ldy < d->k || act < 0 || act > 3) return VSPW_EINVAL;
+    const long long P = (long long)d->n * d->h * d->w;
+    hipStream_t st = vspw_stream(stream);
+    const int ppw = 4;  // pixels per wave: the weight registers are loaded once per wave
+    const int grid = vspw_cdiv(P, 4 * ppw);
+#define FEWOUT(KO) hipLaunchKernelGGL((conv_few_outputs_kernel<KO, 9>), dim3(grid), dim3(256), 0, st, x, ldx, w, bias, y, \
+                                      ldy, d->n, d->h, d->w, d->c, d->kh, d->kw, d->pad, d->pad_w, act, ppw)
+    if (d->k == 1) FEWOUT(1);
+    else if (d->k == 2) FEWOUT(2);
+    else if (d->k == 3) FEWOUT(3);
+    else FEWOUT(4);
+#undef FEWOUT
     return vspw_launch_status();
 }

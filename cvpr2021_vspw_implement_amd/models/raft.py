@@ -28,6 +28,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 # ------------------------------------------------------------------------------------------- parameter containers
 # the update block's Winograd convolutions through the row-fused GEMM where the grid fills the chip (see conv() below)
 _RAFT_WROWS = os.environ.get("VSPW_RAFT_WROWS", "1") == "1"
+_RAFT_THIN = os.environ.get("VSPW_RAFT_THIN", "1") == "1"  # vspw_conv2d_thin for the 256 -> 2 convolution of the flow head
 
 class _ResidualBlock(nn.Module):
     """RAFT_core/extractor.py:6-56 (norm_fn 'instance' or 'batch'); norm3 is also downsample[1], as there."""
@@ -118,6 +119,10 @@ def _conv(x, n, h, w, c, ldx, wt, bias, kh, kw, stride, pad, act, y, ldy):
     ow = (w + 2 * pw - (kw - 1) - 1) // stride + 1
     d = ConvDesc(n, h, w, c, oh, ow, k, kh, kw, stride, ph, 1, pw)
     GEMM_FLOPS["total"] += 2.0 * n * oh * ow * k * kh * kw * c
+    if _RAFT_THIN and int(_C.query("vspw_conv2d_thin_supported", ctypes.byref(d), ldx, ldy)):
+        # 256 -> 2 channels: a direct kernel instead of an MFMA tile that is 97 % padding
+        _C.call("vspw_conv2d_thin", ctypes.byref(d), x, ldx, _p(wt), _p(bias), act, y, ldy, _stream())
+        return oh, ow
     _C.call("vspw_conv2d_fwd_ex", ctypes.byref(d), x, ldx, _p(wt), _p(bias), None, act, y, ldy, _stream())
     return oh, ow
 

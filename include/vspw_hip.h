@@ -70,6 +70,13 @@ int vspw_conv2d_fwd_apply(const vspw_conv_desc* d, const float* y_in, const floa
  * here, with the BN scale folded into the weights and its shift passed as the bias (ops.ConvBNActFn, inference). */
 int vspw_conv2d_fwd_ex(const vspw_conv_desc* d, const float* x, long long ldx, const float* w, const float* bias,
                        const float* addend, int act, float* y, long long ldy, void* stream);
+/* Direct form of a convolution with FEW OUTPUT channels (k <= 4, c % 4 == 0, c >= 64, <= 9 taps, stride 1, undilated,
+ * same-size output): RAFT's FlowHead.conv2 (3x3, 256 -> 2 channels, RAFT_core/update.py:13-14) fills 2 of the 64 columns
+ * of an MFMA tile - one wave per pixel instead.  Arguments as vspw_conv2d_fwd_ex (no addend).  _supported: 0 = take
+ * vspw_conv2d_fwd_ex, 1 = this entry point runs it. */
+int vspw_conv2d_thin_supported(const vspw_conv_desc* d, long long ldx, long long ldy);
+int vspw_conv2d_thin(const vspw_conv_desc* d, const float* x, long long ldx, const float* w, const float* bias, int act,
+                     float* y, long long ldy, void* stream);
 /* dx = conv2d_backward_input(dy, w).  wT is the [c][kh][kw][k] copy of w made by vspw_weight_transpose. */
 int vspw_conv2d_bwd_data(const vspw_conv_desc* d, const float* dy, const float* wT, float* dx, void* stream);
 /* dx = conv2d_backward_input(dy, w) + addend: the gradient arriving over the skip connection (models/resnet.py:75-90:

@@ -139,6 +139,48 @@ def test_conv_ex_slices_padding_activation(dev, kh, kw, pad, c, k, act):
     assert (got[..., :4] == -7.0).all() and (got[..., 4 + k:] == -7.0).all()  # neighbouring slots untouched
 
 
+@pytest.mark.parametrize("kh,kw,pad,c,k,act,form", [
+    (3, 3, (1, 1), 256, 2, 0, 1),   # FlowHead.conv2
+    (3, 3, (1, 1), 64, 1, 1, 1),    # one output, lanes 16-63 idle
+    (1, 1, (0, 0), 384, 4, 2, 1),   # c > 256: two passes over the channels, partial sums parked in y
+    (3, 1, (1, 0), 128, 3, 3, 1),
+    (7, 7, (3, 3), 2, 128, 1, 0),   # BasicMotionEncoder.convf1: stays an implicit GEMM (tools/diag/thin_time.py)
+    (3, 3, (1, 1), 32, 8, 0, 0),    # not thin: the caller keeps vspw_conv2d_fwd_ex
+])
+def test_thin_convolutions_direct_forms(dev, kh, kw, pad, c, k, act, form):
+    """vspw_conv2d_thin (csrc/raft.hip): the few-outputs direct kernel against the numpy convolution, with the input a
+    channel slice of a wider NHWC buffer, the output a slot of another one, ragged pixel counts (the last wave is partial),
+    every activation; vspw_conv2d_thin_supported says whether it runs."""
+    from cvpr2021_vspw_implement_amd import _C
+    from cvpr2021_vspw_implement_amd._C import ConvDesc
+    from cvpr2021_vspw_implement_amd.ops import _p, _stream
+
+    n, h, w = 2, 11, 13
+    ldx, ldy = c + 16, k + 12
+    tag = "thin:%d%d%d%d" % (kh, kw, c, k)
+    xfull = det_input(tag + "x", (n, ldx, h, w))
+    wt = det_input(tag + "w", (k, c, kh, kw), scale=0.2)
+    bias = det_input(tag + "b", (k,))
+    d = ConvDesc(n, h, w, c, h, w, k, kh, kw, 1, pad[0], 1, pad[1])
+    assert int(_C.query("vspw_conv2d_thin_supported", ctypes.byref(d), ldx, ldy)) == form
+    if form == 0:
+        return
+    ref = np_raft.conv2d(xfull[:, 8:8 + c].astype(np.float64), wt.astype(np.float64), bias.astype(np.float64), 1, pad)
+    ref = {0: lambda v: v, 1: np_raft.relu, 2: np_raft.sigmoid, 3: np.tanh}[act](ref)
+    tx = torch.from_numpy(np.ascontiguousarray(xfull.transpose(0, 2, 3, 1))).to(dev)
+    tw = torch.from_numpy(np.ascontiguousarray(wt.transpose(0, 2, 3, 1))).to(dev)
+    tb = torch.from_numpy(bias).to(dev)
+    for b_ in (tb, None):
+        y = torch.full((n, h, w, ldy), -7.0, device=dev)
+        _C.call("vspw_conv2d_thin", ctypes.byref(d), ctypes.c_void_p(tx.data_ptr() + 32), ldx, _p(tw), _p(b_), act,
+                ctypes.c_void_p(y.data_ptr() + 16), ldy, _stream())
+        got = y.cpu().numpy()
+        want = ref if b_ is not None else {0: lambda v: v, 1: np_raft.relu, 2: np_raft.sigmoid, 3: np.tanh}[act](
+            np_raft.conv2d(xfull[:, 8:8 + c].astype(np.float64), wt.astype(np.float64), np.zeros(k), 1, pad))
+        assert np.abs(got[..., 4:4 + k].transpose(0, 3, 1, 2) - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+        assert (got[..., :4] == -7.0).all() and (got[..., 4 + k:] == -7.0).all()  # neighbouring slots untouched
+
+
 def test_raft_full_size_constant_flow_property(dev):
     """At the NetWarp working size (480x856 = 479x853 zero-padded, B = 2, 20 iterations): with the flow head's last
     conv zeroed and its bias set to (a, b) every iteration adds exactly (a, b), so flow_low = 20*(a, b) everywhere and,

@@ -2,6 +2,7 @@
 node, inference folding and the fused conv+BN+activation node with its backward fusions (BNLink, deferred apply)."""
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -233,6 +234,11 @@ def _conv_bn_folded(x, w, cbias, gamma, beta, running_mean, running_var, residua
     key = tuple((t.data_ptr(), t._version) if t is not None else None for t in srcs) + (float(eps), _infer_fold["gen"])
     ent = _infer_fold["cache"].get(id(w))
     st = _stream()
+    # (address, version) identify a tensor only while it is ALIVE: a model that was dropped hands its storage - and the
+    # ids of its Python objects - to the next one of the same shapes (seen in the GPU suite: ResNet-18's layer1 weights
+    # served to ResNet-101's layer1).  An entry is valid only for the very tensor objects it was derived from.
+    if ent is not None and any((r() if r is not None else None) is not t for r, t in zip(ent[4], srcs)):
+        ent = None
     if ent is None or ent[0] != key:
         coef = torch.empty((4, k), device=x.device, dtype=torch.float32)
         _C.call("vspw_bn_eval_coeffs", _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(coef[0]),
@@ -240,8 +246,11 @@ def _conv_bn_folded(x, w, cbias, gamma, beta, running_mean, running_var, residua
         wf = torch.empty((k, kh, kw, c), device=x.device, dtype=torch.float32)
         bf = torch.empty(k, device=x.device, dtype=torch.float32)
         _C.call("vspw_bn_fold_weights", _p(w), _p(cbias), _p(coef[2]), _p(coef[3]), _p(wf), _p(bf), k, kh * kw * c, st)
-        ent = [key, wf, bf, None]
+        ent = [key, wf, bf, None, tuple(weakref.ref(t) if t is not None else None for t in srcs)]
         _infer_fold["cache"][id(w)] = ent
+        if len(_infer_fold["cache"]) > 512:  # entries of weights that no longer exist
+            for k_ in [k_ for k_, e_ in _infer_fold["cache"].items() if e_[4][0]() is None]:
+                del _infer_fold["cache"][k_]
     _, wf, bf = ent[0], ent[1], ent[2]
     d = _conv_desc(x, k, kh, kw, stride, pad, dil)
     z = empty_nhwc(d.n, k, d.oh, d.ow, x.device)
@@ -412,17 +421,25 @@ class ConvBNActFn(torch.autograd.Function):
             # the consumer's data gradient already masked dz with this node's ReLU and left the two reductions behind
             _bn_fusion["fused_nodes"] += 1
             part = link.partials
-            _C.call("vspw_bn_bwd_reduce_partials_f32", _p(part), part.shape[0], c, _p(sums), _p(dgamma), _p(dbeta), st)
-            if ctx.training and ctx.world != 1:
-                _all_reduce_sums(sums)
             pointwise = d.kh == 1 and d.kw == 1 and d.stride == 1 and d.pad == 0 and d.pad_w == 0
-            if (_bn_fusion["affine"] and pointwise and not ctx.has_cbias and c >= _bn_fusion["affine_min_c"]
-                    and _C.query("vspw_conv2d_bwd_aff_supported", ctypes.byref(d)) == 1):
+            affine = (_bn_fusion["affine"] and pointwise and not ctx.has_cbias and c >= _bn_fusion["affine_min_c"]
+                      and _C.query("vspw_conv2d_bwd_aff_supported", ctypes.byref(d)) == 1)
+            exchange = ctx.training and ctx.world != 1
+            if affine and not exchange:  # reduction and coefficients in one launch (nothing to exchange in between)
+                coef = torch.empty((3, c), device=dev, dtype=torch.float32)
+                _C.call("vspw_bn_bwd_reduce_partials_coeffs_f32", _p(part), part.shape[0], c, ctypes.c_double(ctx.count),
+                        _p(gamma), _p(mean), _p(invstd), train, _p(sums), _p(dgamma), _p(dbeta), _p(coef), st)
+            else:
+                _C.call("vspw_bn_bwd_reduce_partials_f32", _p(part), part.shape[0], c, _p(sums), _p(dgamma), _p(dbeta), st)
+                if exchange:
+                    _all_reduce_sums(sums)
+            if affine:
                 # pointwise conv: BatchNorm's backward apply becomes an affine map staged by the two gradient GEMMs of
                 # this conv - dy (the gradient w.r.t. the conv output) is never written
-                coef = torch.empty((3, c), device=dev, dtype=torch.float32)
-                _C.call("vspw_bn_bwd_affine_coeffs", _p(sums), ctypes.c_double(ctx.count), _p(gamma), _p(mean),
-                        _p(invstd), _p(coef), c, train, st)
+                if exchange:
+                    coef = torch.empty((3, c), device=dev, dtype=torch.float32)
+                    _C.call("vspw_bn_bwd_affine_coeffs", _p(sums), ctypes.c_double(ctx.count), _p(gamma), _p(mean),
+                            _p(invstd), _p(coef), c, train, st)
                 aff = (y, coef)
                 dy = dz
                 _bn_fusion["affine_nodes"] += 1

@@ -233,6 +233,53 @@ __global__ __launch_bounds__(1024) void reduce_partials_pg_kernel(const T* __res
     }
 }
 
+// reduce_partials_pg_kernel<float> + bn_bwd_affine_coeffs_kernel in one launch (the pointwise nodes whose BatchNorm-backward
+// apply is staged by their gradient GEMMs: 30 per TCB-PSP step): a thread column owns channel i and BOTH of its statistics.
+// Same partition of the partial rows (z = ty, ty + 32, ...) and the same order of the 32 group sums as the two-launch form:
+// bit-identical sums, parameter gradients and coefficients.
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_coeffs_kernel(
+    const float* __restrict__ part, int splits, int c, double inv_count, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ invstd, int training, double* __restrict__ sums,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ coef) {
+    __shared__ double red[2][32][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + tx;
+    const int n = 2 * c;
+    double a = 0, b = 0;
+    if (i < c) {
+#pragma unroll 8
+        for (int z = ty; z < splits; z += 32) {
+            a += (double)part[(size_t)z * n + i];
+            b += (double)part[(size_t)z * n + c + i];
+        }
+    }
+    red[0][ty][tx] = a;
+    red[1][ty][tx] = b;
+    __syncthreads();
+    if (ty != 0 || i >= c) return;
+    double sg = 0, sgx = 0;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        sg += red[0][j][tx];
+        sgx += red[1][j][tx];
+    }
+    sums[i] = sg;
+    sums[c + i] = sgx;
+    if (dbeta) dbeta[i] = (float)sg;
+    if (dgamma) dgamma[i] = (float)sgx;
+    const double is = invstd[i];
+    const double av = (gamma ? (double)gamma[i] : 1.0) * is;
+    double bv = 0.0, kv = 0.0;
+    if (training) {
+        const double mg = sg * inv_count, mgx = sgx * inv_count;
+        bv = -av * is * mgx;
+        kv = av * ((double)mean[i] * is * mgx - mg);
+    }
+    coef[i] = (float)av;
+    coef[c + i] = (float)bv;
+    coef[2 * c + i] = (float)kv;
+}
+
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ rmean,
                                    float* __restrict__ rvar, float momentum, float eps, float* __restrict__ mean,
@@ -646,6 +693,15 @@ extern "C" int vspw_bn_bwd_reduce_partials_f32(const float* part, int tiles, int
     if (!part || !sums || tiles <= 0 || c <= 0) return VSPW_EINVAL;
     hipLaunchKernelGGL(reduce_partials_pg_kernel<float>, dim3(vspw_cdiv(2 * c, 32)), dim3(1024), 0, vspw_stream(stream),
                        part, sums, dgamma, dbeta, tiles, c);
+    return vspw_launch_status();
+}
+
+extern "C" int vspw_bn_bwd_reduce_partials_coeffs_f32(const float* part, int tiles, int c, double count, const float* gamma,
+                                                      const float* mean, const float* invstd, int training, double* sums,
+                                                      float* dgamma, float* dbeta, float* coef, void* stream) {
+    if (!part || !sums || !mean || !invstd || !coef || tiles <= 0 || c <= 0 || count <= 0) return VSPW_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_reduce_coeffs_kernel, dim3(vspw_cdiv(c, 32)), dim3(1024), 0, vspw_stream(stream), part, tiles, c,
+                       1.0 / count, gamma, mean, invstd, training, sums, dgamma, dbeta, coef);
     return vspw_launch_status();
 }
 

@@ -109,6 +109,11 @@ int vspw_conv2d_bwd_weight(const vspw_conv_desc* d, const float* dy, const float
  * n*oh*ow % 32 == 0 for the weight gradient. */
 int vspw_bn_bwd_affine_coeffs(const double* sums, double count, const float* gamma, const float* mean,
                               const float* invstd, float* coef, int c, int training, void* stream);
+/* vspw_bn_bwd_reduce_partials_f32 + vspw_bn_bwd_affine_coeffs in one launch (single rank: no exchange of the sums in
+ * between) - bit-identical to the two-launch form. */
+int vspw_bn_bwd_reduce_partials_coeffs_f32(const float* part, int tiles, int c, double count, const float* gamma,
+                                           const float* mean, const float* invstd, int training, double* sums,
+                                           float* dgamma, float* dbeta, float* coef, void* stream);
 int vspw_conv2d_bwd_data_aff(const vspw_conv_desc* d, const float* g, const float* y, const float* coef, const float* wT,
                              const float* addend, const float* relu_src, const float* bn_y, const float* bn_mean,
                              const float* bn_invstd, float* dx, float* stat_part, void* stream);

@@ -838,3 +838,61 @@ def test_flow_plumbing_gathers_match_aten(dev, hw, out):
     mean, std = torch.FloatTensor([0.485, 0.456, 0.406]), torch.FloatTensor([0.229, 0.224, 0.225])
     un = ops.unnormalize_rgb(img.to(dev), std.tolist(), mean.tolist(), 255.0)
     assert torch.equal(un.cpu(), (img * std.view(1, 3, 1, 1) + mean.view(1, 3, 1, 1)) * 255.0)
+
+
+@pytest.mark.parametrize("tiles,c,training", [(375, 1024, 1), (94, 256, 1), (7, 40, 1), (33, 512, 0)])
+def test_bn_backward_partial_reduction_with_coefficients_is_bit_identical(dev, tiles, c, training):
+    """vspw_bn_bwd_reduce_partials_coeffs_f32 = vspw_bn_bwd_reduce_partials_f32 followed by vspw_bn_bwd_affine_coeffs, in
+    one launch: sums (fp64), dgamma / dbeta and the three coefficient rows must be the SAME bits."""
+    from cvpr2021_vspw_implement_amd import _C
+    from cvpr2021_vspw_implement_amd.ops import _p, _stream
+
+    g = torch.Generator().manual_seed(tiles + c)
+    part = torch.randn(tiles, 2, c, generator=g).to(dev)
+    gamma = (torch.rand(c, generator=g) + 0.5).to(dev)
+    mean, invstd = torch.randn(c, generator=g).to(dev), (torch.rand(c, generator=g) + 0.5).to(dev)
+    count = 36000.0
+    st = _stream()
+    s0 = torch.empty(2, c, device=dev, dtype=torch.float64)
+    dg0, db0, k0 = torch.empty(c, device=dev), torch.empty(c, device=dev), torch.empty(3, c, device=dev)
+    _C.call("vspw_bn_bwd_reduce_partials_f32", _p(part), tiles, c, _p(s0), _p(dg0), _p(db0), st)
+    _C.call("vspw_bn_bwd_affine_coeffs", _p(s0), ctypes.c_double(count), _p(gamma), _p(mean), _p(invstd), _p(k0), c, training, st)
+    s1 = torch.empty(2, c, device=dev, dtype=torch.float64)
+    dg1, db1, k1 = torch.empty(c, device=dev), torch.empty(c, device=dev), torch.empty(3, c, device=dev)
+    _C.call("vspw_bn_bwd_reduce_partials_coeffs_f32", _p(part), tiles, c, ctypes.c_double(count), _p(gamma), _p(mean),
+            _p(invstd), training, _p(s1), _p(dg1), _p(db1), _p(k1), st)
+    torch.cuda.synchronize()
+    for a, b, what in ((s0, s1, "sums"), (dg0, dg1, "dgamma"), (db0, db1, "dbeta"), (k0, k1, "coef")):
+        assert torch.equal(a, b), what
+    ref = part.double().sum(0)
+    assert torch.allclose(s1, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_inference_fold_cache_is_not_served_to_a_new_model_in_recycled_storage(dev):
+    """Regression (round 5, seen once in the full GPU suite): the folded conv+BN weights of inference were cached under
+    (id, address, version) of the tensors they derive from - identities that a NEW model built after the old one was
+    dropped inherits together with its storage.  Six generations of same-shape modules, each dropped before the next is
+    built: the folded path must follow the unfolded one every time."""
+    import gc
+
+    from cvpr2021_vspw_implement_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 12, 13, generator=g).to(dev)
+    for gen in range(6):
+        w = (torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(dev).contiguous(memory_format=torch.channels_last)
+        gamma, beta = (torch.rand(64, generator=g) + 0.5).to(dev), torch.randn(64, generator=g).to(dev)
+        rm, rv = torch.randn(64, generator=g).to(dev), (torch.rand(64, generator=g) + 0.5).to(dev)
+        out = {}
+        for folded in (True, False):
+            ops.set_inference_folding(folded)
+            try:
+                with torch.no_grad():
+                    out[folded] = ops.conv_bn_act(x, w, None, gamma, beta, rm, rv, pad=1, training=False, relu=True).cpu()
+            finally:
+                ops.set_inference_folding(True)
+        err = float((out[True] - out[False]).abs().max())
+        assert err < 1e-4 * float(out[False].abs().max() + 1.0), (gen, err)
+        del w, gamma, beta, rm, rv, out
+        gc.collect()
+        torch.cuda.empty_cache() if gen % 2 else None

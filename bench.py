@@ -411,6 +411,8 @@ def main():
     # shader clock the chip sustained inside the forward / data-gradient GEMM launches of the timed steps (workgroup 0 of
     # every launch: s_memtime cycles / 100 MHz wall ticks); the fp32 MFMA peak is quoted at 2.4 GHz
     sustained_ghz = (clock_probe[0] / (clock_probe[1] * 10.0)) if clock_probe[1] else None
+    if sustained_ghz is not None and not (0.5 < sustained_ghz < 4.0):
+        sustained_ghz = None  # (the probe keeps one start stamp per device: two NT launches overlapping on different streams spoil it)
     last_loss = float(loss.item())
     model.check_exchange()  # a peer statistics exchange that timed out poisons the step with NaN: fail loudly
     if world > 1:

@@ -139,7 +139,8 @@ def test_winograd_path_equals_direct_path_in_a_fused_chain(dev, dil, h, w, wino_
     (4, 2048, 24, 32, 256, False),  # interior 96 / 128-row tiles, 8 chains of 256
     (2, 1024, 12, 13, 200, True),   # ragged rows and columns: guarded flush, bias added once
     (3, 512, 20, 20, 1024, False),  # two chains forward, four in the data gradient (K = output channels there)
-    (1, 4096, 40, 48, 512, False),  # K > 1024 on the 128x128 tile: two LDS buffers, flush scratch in the dead one
+    (1, 4096, 40, 48, 512, False),  # 16 chains on the small-problem 64x64 tile
+    (4, 2048, 64, 64, 512, False),  # 16 384 rows: the 128x128 tile with TWO LDS buffers (K > 1024), flush scratch in the dead one
 ])
 def test_pointwise_two_level_accumulation(dev, n, c, h, w, k, bias):
     """K >= 2*chunk pointwise GEMMs sum K/chunk chains of chunk terms, the finished chains parked in the output tile
@@ -186,12 +187,23 @@ def test_pointwise_two_level_accumulation(dev, n, c, h, w, k, bias):
             assert torch.equal(out[0][0][idx], out[256][0][idx]), what  # short reductions: one chain either way
 
 
+@pytest.fixture(params=[0, 256], ids=["one-chain", "chains-of-256"])
+def accum_chunk(request):
+    """Run a test under both summation policies of the long pointwise reductions (vspw_set_accum_chunk): the fused
+    epilogues / staged operands must compose with the parked partial sums."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    prev = ops.set_accum_chunk(request.param)
+    yield request.param
+    ops.set_accum_chunk(prev)
+
+
 @pytest.mark.parametrize("n,c,h,w,k", [(2, 256, 16, 24, 64),   # interior 128x128 / 96-row tiles: accumulators seeded
                                        (1, 64, 9, 13, 32),     # ragged: every tile takes the guarded epilogue
                                        (3, 1024, 20, 20, 256),  # forward K = 1024: four parked chains
                                        (2, 256, 16, 24, 1024),  # data gradient K = 1024: parked chains + skip + BN front
                                        (1, 128, 9, 13, 512)])   # ... on ragged tiles (guarded flush)
-def test_conv_bn_act_skip_gradient_is_folded_into_dgrad(dev, n, c, h, w, k):
+def test_conv_bn_act_skip_gradient_is_folded_into_dgrad(dev, n, c, h, w, k, accum_chunk):
     """Bottleneck entry (models/resnet.py:75-90): x feeds conv1 AND the skip.  With skip_out the skip gradient is added
     in conv1's data-gradient epilogue (vspw_conv2d_bwd_data_acc); the total must equal autograd's sum of both paths."""
     from cvpr2021_vspw_implement_amd import ops
@@ -220,7 +232,7 @@ def test_conv_bn_act_skip_gradient_is_folded_into_dgrad(dev, n, c, h, w, k):
                                                  (3, 32, 1024, 20, 20, 256, True),  # layer-3 shape: 96-row tiles
                                                  (1, 32, 64, 9, 13, 32, True),      # ragged rows: clamped A rows
                                                  (2, 16, 48, 10, 10, 32, False)])   # C % 32 != 0: plain apply pass
-def test_block_output_evaluated_by_the_next_conv1(dev, n, cm, c, h, w, k, fused):
+def test_block_output_evaluated_by_the_next_conv1(dev, n, cm, c, h, w, k, fused, accum_chunk):
     """A residual block's relu(bn3(conv3(u)) + skip) left to the next block's conv1 (models/resnet.py:83-90 then :75,
     ops._fwd_apply / vspw_conv2d_fwd_apply): the block output, conv1's output and every gradient against autograd on
     the plain composition; the fused kernel is taken exactly when the geometry allows it."""

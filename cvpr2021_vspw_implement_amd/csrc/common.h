@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/vspw_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -21,11 +22,15 @@ static inline hipStream_t vspw_stream(void* s) { return reinterpret_cast<hipStre
 
 static inline int vspw_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-// Grid size for HBM-bound grid-stride kernels: enough blocks to fill 256 CUs x 8.
+// Grid size for HBM-bound grid-stride kernels: 256 CUs x 4 workgroups of 256 threads.  (Measured on the BatchNorm apply at the
+// layer-3 shapes, tools/diag/bn_bw.py, rotating buffers: 512 blocks 4.1-4.9 TB/s, 1024 4.9-5.8, 2048 - the value of rounds
+// 1-4 - 4.6-5.7, 16384 4.7-5.8; the training step: 82.1 -> 81.75 ms.  Two float4 per stream in flight per thread was
+// tried too and LOSES 8-12 %.)
 static inline int vspw_stream_grid(long long work_items, int block) {
+    static const long long cap = getenv("VSPW_STREAM_BLOCKS") ? atoll(getenv("VSPW_STREAM_BLOCKS")) : 256 * 4;  // (env: experiments)
     long long g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
-    if (g > 256 * 8) g = 256 * 8;
+    if (g > cap) g = cap;
     return (int)g;
 }
 

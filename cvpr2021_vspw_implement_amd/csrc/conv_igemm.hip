@@ -2159,9 +2159,62 @@ extern "C" size_t vspw_conv2d_stats_partials(const vspw_conv_desc* d) {
     return (size_t)((p.m + rows - 1) / rows);
 }
 
+// Few-row pointwise GEMM (the pyramid-pool branches: 2 ... 72 pooled pixels x 2048 -> 512 channels, models/models.py:
+// 905-912 / clip_psp.py:45-56): through the MFMA tiles these are 8 workgroups walking 64 K-tiles each - 58-62 us of pure
+// latency per branch (profiles/r05_final_gemm_shapes.csv).  Here a WAVE owns one output channel: its weight row lives in
+// registers (lane = 4 consecutive k, +256 per pass), the input rows stream through L2, one wave_sum per output element.
+#define SKINNY_MAX_ROWS 128
+#define SKINNY_ROWS_PER_WG 24
+template <int KP>  // KP = K / 256 passes
+__global__ __launch_bounds__(256) void skinny_pointwise_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ bias, float* __restrict__ y,
+                                                               int m, int n, int k) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 4 + wave;
+    if (col >= n) return;
+    f32x4 wr[KP];
+#pragma unroll
+    for (int j = 0; j < KP; ++j) wr[j] = *reinterpret_cast<const f32x4*>(w + (size_t)col * k + j * 256 + lane * 4);
+    const float bv = bias ? bias[col] : 0.f;
+    const int r0 = blockIdx.y * SKINNY_ROWS_PER_WG, r1 = min(m, r0 + SKINNY_ROWS_PER_WG);
+    for (int r = r0; r < r1; ++r) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < KP; ++j) acc += wr[j] * *reinterpret_cast<const f32x4*>(x + (size_t)r * k + j * 256 + lane * 4);
+        const float s = wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+        if (lane == 0) y[(size_t)r * n + col] = s + bv;
+    }
+}
+
+static bool skinny_ok(const vspw_conv_desc* d, const float* stat_part) {
+    static const int enabled = getenv("VSPW_SKINNY") ? atoi(getenv("VSPW_SKINNY")) : 1;
+    const long long m = (long long)d->n * d->oh * d->ow;
+    return enabled && stat_part == nullptr && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->pad_w == 0 &&
+           m <= SKINNY_MAX_ROWS && d->c % 256 == 0 && d->c >= 512 && d->c <= 4096 && d->k >= 64;
+}
+
 extern "C" int vspw_conv2d_fwd(const vspw_conv_desc* d, const float* x, const float* w, const float* bias,
                                float* y, float* stat_part, void* stream) {
     if (!conv_geometry_ok(d) || !x || !w || !y) return VSPW_EINVAL;
+    if (skinny_ok(d, stat_part)) {
+        const int m = d->n * d->oh * d->ow;
+        const dim3 grid(vspw_cdiv(d->k, 4), vspw_cdiv(m, SKINNY_ROWS_PER_WG));
+        hipStream_t st = vspw_stream(stream);
+#define SKINNY(KP) hipLaunchKernelGGL((skinny_pointwise_kernel<KP>), grid, dim3(256), 0, st, x, w, bias, y, m, d->k, d->c)
+        switch (d->c / 256) {
+            case 2: SKINNY(2); break;
+            case 3: SKINNY(3); break;
+            case 4: SKINNY(4); break;
+            case 6: SKINNY(6); break;
+            case 8: SKINNY(8); break;
+            case 12: SKINNY(12); break;
+            case 16: SKINNY(16); break;
+            default: goto gemm;
+        }
+#undef SKINNY
+        return vspw_launch_status();
+    }
+gemm:
     IgemmNT p;
     if (!fill_fwd_params(d, p)) return VSPW_EINVAL;
     p.src = x; p.wt = w; p.bias = bias; p.dst = y; p.stat_part = stat_part;

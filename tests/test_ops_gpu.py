@@ -36,6 +36,10 @@ CONV_CASES = [
     (2, 256, 13, 17, 128, 3, 1, 2, 2, True),   # layer3 style, bias
     (3, 128, 9, 10, 128, 3, 1, 1, 1, False),   # undilated, one odd side
     (1, 1024, 6, 7, 512, 3, 1, 1, 1, False),   # deepsup shape class: 9216-long direct reduction
+    # few-row pointwise GEMMs of the pyramid-pool branches (skinny_pointwise_kernel: a wave per output channel)
+    (2, 2048, 1, 1, 512, 1, 1, 0, 1, False),   # scale-1 branch: 2 rows
+    (2, 2048, 6, 6, 512, 1, 1, 0, 1, False),   # scale-6 branch: 72 rows = three row groups
+    (3, 768, 5, 5, 66, 1, 1, 0, 1, True),      # 75 rows, 3 passes over K, ragged output-channel count, bias
 ]
 
 

@@ -35,6 +35,9 @@ _wino = {"enabled": os.environ.get("VSPW_WINOGRAD", "1") == "1", "min_c": int(os
          "rows": os.environ.get("VSPW_WINO_ROWS", "1") == "1"}
 
 
+_strided_pw = {"enabled": os.environ.get("VSPW_STRIDED_PW_DGRAD", "1") == "1"}  # compact GEMM + scatter (conv2d_backward_data)
+
+
 def set_accum_chunk(k):
     """Two-level accumulation of the pointwise GEMMs with K >= 2k (csrc/conv_igemm.hip, vspw_set_accum_chunk): k terms
     per fp32 chain (multiple of 32), 0 = one k-sequential chain (the library default).  Returns the previous setting."""
@@ -339,6 +342,17 @@ def conv2d_backward_data(dy, w, d, addend=None, bn_front=None, aff=None):
             _C.call("vspw_conv2d_bwd_data_bn", ctypes.byref(d), _p(dy), _p(wT), _p(addend), _p(z), _p(link.y),
                     _p(link.mean), _p(link.invstd), _p(dx), _p(part), _stream())
         link.partials, link.g = part, dx
+        return dx
+    if (addend is None and _strided_pw["enabled"] and kh == 1 and kw == 1 and d.stride > 1 and d.pad == 0 and d.pad_w == 0
+            and d.c % 4 == 0 and d.k % 4 == 0):
+        # strided pointwise conv (the stride-2 downsample): only every stride-th input pixel receives a gradient - a plain
+        # GEMM on the OUTPUT pixels, then a scatter into the zero-filled input grid, instead of the data-gradient gather
+        # that multiplies zeros for three quarters of its MFMAs
+        dc = ConvDesc(d.n, d.oh, d.ow, d.c, d.oh, d.ow, d.k, 1, 1, 1, 0, 1, 0)
+        tmp = empty_nhwc(d.n, d.c, d.oh, d.ow, dy.device)
+        with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "dgrad")):
+            _C.call("vspw_conv2d_bwd_data", ctypes.byref(dc), _p(dy), _p(wT), _p(tmp), _stream())
+        _C.call("vspw_strided_scatter_nhwc", _p(tmp), _p(dx), d.n, d.oh, d.ow, d.h, d.w, d.c, d.stride, _stream())
         return dx
     with _Timed("igemm_nt_kernel", _conv_flops(d), _conv_tag(d, "dgrad")):
         if addend is None:

@@ -2186,35 +2186,34 @@ __global__ __launch_bounds__(256) void skinny_pointwise_kernel(const float* __re
     }
 }
 
-static bool skinny_ok(const vspw_conv_desc* d, const float* stat_part) {
+// y [m][nout] = x [m][kred] . w [nout][kred]^T (+ bias): true when the launch was issued (few rows, a reduction of 2-16 x 256)
+static bool launch_skinny(const vspw_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int nout,
+                          int kred, hipStream_t st) {
     static const int enabled = getenv("VSPW_SKINNY") ? atoi(getenv("VSPW_SKINNY")) : 1;
     const long long m = (long long)d->n * d->oh * d->ow;
-    return enabled && stat_part == nullptr && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->pad_w == 0 &&
-           m <= SKINNY_MAX_ROWS && d->c % 256 == 0 && d->c >= 512 && d->c <= 4096 && d->k >= 64;
+    if (!enabled || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->pad_w != 0 || m > SKINNY_MAX_ROWS ||
+        kred % 256 != 0 || kred < 512 || kred > 4096 || nout < 64)
+        return false;
+    const dim3 grid(vspw_cdiv(nout, 4), vspw_cdiv(m, SKINNY_ROWS_PER_WG));
+#define SKINNY(KP) hipLaunchKernelGGL((skinny_pointwise_kernel<KP>), grid, dim3(256), 0, st, x, w, bias, y, (int)m, nout, kred)
+    switch (kred / 256) {
+        case 2: SKINNY(2); break;
+        case 3: SKINNY(3); break;
+        case 4: SKINNY(4); break;
+        case 6: SKINNY(6); break;
+        case 8: SKINNY(8); break;
+        case 12: SKINNY(12); break;
+        case 16: SKINNY(16); break;
+        default: return false;
+    }
+#undef SKINNY
+    return true;
 }
 
 extern "C" int vspw_conv2d_fwd(const vspw_conv_desc* d, const float* x, const float* w, const float* bias,
                                float* y, float* stat_part, void* stream) {
     if (!conv_geometry_ok(d) || !x || !w || !y) return VSPW_EINVAL;
-    if (skinny_ok(d, stat_part)) {
-        const int m = d->n * d->oh * d->ow;
-        const dim3 grid(vspw_cdiv(d->k, 4), vspw_cdiv(m, SKINNY_ROWS_PER_WG));
-        hipStream_t st = vspw_stream(stream);
-#define SKINNY(KP) hipLaunchKernelGGL((skinny_pointwise_kernel<KP>), grid, dim3(256), 0, st, x, w, bias, y, m, d->k, d->c)
-        switch (d->c / 256) {
-            case 2: SKINNY(2); break;
-            case 3: SKINNY(3); break;
-            case 4: SKINNY(4); break;
-            case 6: SKINNY(6); break;
-            case 8: SKINNY(8); break;
-            case 12: SKINNY(12); break;
-            case 16: SKINNY(16); break;
-            default: goto gemm;
-        }
-#undef SKINNY
-        return vspw_launch_status();
-    }
-gemm:
+    if (stat_part == nullptr && launch_skinny(d, x, w, bias, y, d->k, d->c, vspw_stream(stream))) return vspw_launch_status();
     IgemmNT p;
     if (!fill_fwd_params(d, p)) return VSPW_EINVAL;
     p.src = x; p.wt = w; p.bias = bias; p.dst = y; p.stat_part = stat_part;
@@ -2348,6 +2347,9 @@ static bool fill_bwd_data_params(const vspw_conv_desc* d, IgemmNT& p) {
 static int conv2d_bwd_data_impl(const vspw_conv_desc* d, const float* dy, const float* wT, const float* addend,
                                 float* dx, void* stream, const BnFront* bn, const AffA* aff) {
     if (!conv_geometry_ok(d) || !dy || !wT || !dx) return VSPW_EINVAL;
+    // (few rows: dx [m][Cin] = dy [m][Cout] . wT [Cin][Cout]^T is the same skinny product as the forward pass)
+    if (!addend && !bn && !aff && launch_skinny(d, dy, wT, nullptr, dx, d->c, d->k, vspw_stream(stream)))
+        return vspw_launch_status();
     IgemmNT p;
     if (!fill_bwd_data_params(d, p)) return VSPW_EINVAL;
     p.src = dy; p.wt = wT; p.dst = dx; p.addend = addend;

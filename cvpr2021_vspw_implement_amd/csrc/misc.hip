@@ -530,6 +530,38 @@ extern "C" int vspw_plane_shift(const float* in, float* out, long long planes, i
     return vspw_launch_status();
 }
 
+// dst [n][h][w][c] = src [n][oh][ow][c] at the pixels (y, x) = (s*oy, s*ox), zero elsewhere: the data gradient of a strided
+// POINTWISE convolution (the 1x1 stride-2 downsample of layer2.0, models/resnet.py:125-131) is a plain GEMM on the output
+// pixels followed by this scatter - through the implicit GEMM's data-gradient gather three quarters of the MFMA work
+// multiply zeros (34 TFLOP/s, 275 us; compact GEMM + scatter: ~115 us).
+__global__ __launch_bounds__(256) void strided_scatter_kernel(const float* __restrict__ src, float* __restrict__ dst, int n,
+                                                              int oh, int ow, int h, int w, int c4, int stride) {
+    const long long total = (long long)n * h * w * c4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c4);
+        long long r = i / c4;
+        const int x = (int)(r % w);
+        r /= w;
+        const int y = (int)(r % h);
+        const int img = (int)(r / h);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y % stride == 0 && x % stride == 0) {
+            const int oy = y / stride, ox = x / stride;
+            if (oy < oh && ox < ow) v = reinterpret_cast<const f32x4*>(src)[(((long long)img * oh + oy) * ow + ox) * c4 + ch];
+        }
+        reinterpret_cast<f32x4*>(dst)[i] = v;
+    }
+}
+
+extern "C" int vspw_strided_scatter_nhwc(const float* src, float* dst, int n, int oh, int ow, int h, int w, int c, int stride,
+                                         void* stream) {
+    if (!src || !dst || n < 1 || oh < 1 || ow < 1 || h < 1 || w < 1 || c < 4 || c % 4 || stride < 1) return VSPW_EINVAL;
+    const long long total = (long long)n * h * w * (c / 4);
+    hipLaunchKernelGGL(strided_scatter_kernel, dim3(vspw_stream_grid(total, 256)), dim3(256), 0, vspw_stream(stream), src, dst,
+                       n, oh, ow, h, w, c / 4, stride);
+    return vspw_launch_status();
+}
+
 extern "C" int vspw_unnormalize_rgb(const float* in, float* out, int n, long long hw, float s0, float s1, float s2,
                                     float m0, float m1, float m2, float post, void* stream) {
     if (!in || !out || n < 1 || hw < 1) return VSPW_EINVAL;

@@ -498,6 +498,11 @@ int vspw_nl_dot(const float* q, const float* k, const float* v, float* out, int 
                 size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------- flow plumbing (misc.hip) ---------- */
+/* dst [n][h][w][c] = src [n][oh][ow][c] at pixels (stride*oy, stride*ox), zero elsewhere (c % 4 == 0): second half of the
+ * data gradient of a strided pointwise convolution (models/resnet.py:125-131, the 1x1 stride-2 downsample) computed as a plain
+ * GEMM on the output pixels (vspw_conv2d_bwd_data with a stride-1 descriptor of the OUTPUT size) + this scatter. */
+int vspw_strided_scatter_nhwc(const float* src, float* dst, int n, int oh, int ow, int h, int w, int c, int stride,
+                              void* stream);
 /* Plane gathers on NCHW data [planes][h][w] around the flow network of the NetWarp heads:
  *   vspw_nearest_resize_fwd / bwd  F.interpolate(flow, size, mode='nearest') and its adjoint (models/netwarp.py:199,214;
  *                                  models/netwarp_ocr.py:252): src = min(floor(dst * (float)in / out), in - 1);

@@ -912,3 +912,19 @@ def test_inference_fold_cache_is_not_served_to_a_new_model_in_recycled_storage(d
         del w, gamma, beta, rm, rv, out
         gc.collect()
         torch.cuda.empty_cache() if gen % 2 else None
+
+
+@pytest.mark.parametrize("n,oh,ow,h,w,c,stride", [(2, 11, 12, 21, 23, 8, 2), (1, 4, 5, 10, 13, 64, 3), (3, 7, 7, 7, 7, 4, 1)])
+def test_strided_scatter_is_the_adjoint_of_strided_sampling(dev, n, oh, ow, h, w, c, stride):
+    """vspw_strided_scatter_nhwc (second half of the strided pointwise data gradient): dst[:, s*oy, s*ox] = src, zero
+    elsewhere - bit-exact against indexing, for odd extents and a trailing rim that no output pixel reaches."""
+    from cvpr2021_vspw_implement_amd import _C
+    from cvpr2021_vspw_implement_amd.ops import _p, _stream
+
+    g = torch.Generator().manual_seed(h * w + c)
+    src = torch.randn(n, oh, ow, c, generator=g)
+    want = torch.zeros(n, h, w, c)
+    want[:, ::stride, ::stride][:, :oh, :ow] = src
+    dst = torch.full((n, h, w, c), -3.0, device=dev)
+    _C.call("vspw_strided_scatter_nhwc", _p(src.to(dev)), _p(dst), n, oh, ow, h, w, c, stride, _stream())
+    assert torch.equal(dst.cpu(), want)

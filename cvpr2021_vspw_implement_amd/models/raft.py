@@ -28,6 +28,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 # ------------------------------------------------------------------------------------------- parameter containers
 # the update block's Winograd convolutions through the row-fused GEMM where the grid fills the chip (see conv() below)
 _RAFT_WROWS = os.environ.get("VSPW_RAFT_WROWS", "1") == "1"
+_RAFT_PADK = os.environ.get("VSPW_RAFT_PADK", "1") == "1"  # convc1's 324-long reduction zero-padded to 352 (a multiple of 32)
 _RAFT_THIN = os.environ.get("VSPW_RAFT_THIN", "1") == "1"  # vspw_conv2d_thin for the 256 -> 2 convolution of the flow head
 
 class _ResidualBlock(nn.Module):
@@ -182,6 +183,13 @@ class RAFT(nn.Module):
             z, r = getattr(g, "convz" + sfx), getattr(g, "convr" + sfx)
             P["update_block.gru.convzr" + sfx] = (torch.cat([_pack(z), _pack(r)], 0).contiguous(),
                                                   torch.cat([z.bias.detach(), r.bias.detach()], 0).contiguous())
+        # convc1 reduces over the 324 correlation taps: 324 % 32 != 0 sends it to the generic gather kernel (31 us per
+        # iteration).  Zero-padded to 352 columns (the lookup buffer carries 28 zero columns) it is a plain pointwise GEMM.
+        if _RAFT_PADK:
+            wc, bc = P["update_block.encoder.convc1"]
+            wp = torch.zeros((wc.shape[0], 1, 1, 352), device=wc.device, dtype=torch.float32)
+            wp[..., : wc.shape[3]] = wc
+            P["update_block.encoder.convc1"] = (wp.contiguous(), bc)
         c2 = self.cnet.conv2
         w2, b2 = _pack(c2), c2.bias.detach()
         P["cnet.conv2.net"] = (w2[: self.hidden_dim].contiguous(), b2[: self.hidden_dim].contiguous())
@@ -317,7 +325,8 @@ class RAFT(nn.Module):
             lh, lw = lh // 2, lw // 2
 
         flow = torch.zeros((rows, 2), **f32)
-        corr = torch.empty((rows, 324), **f32)
+        ldc = 352 if _RAFT_PADK else 324
+        corr = torch.zeros((rows, ldc), **f32)  # (columns 324 .. ldc stay zero: see _pack_all)
         cor1 = torch.empty((rows, 256), **f32)
         CF = torch.empty((rows, 256), **f32)  # [cor(192) | flo(64)]
         flo1 = torch.empty((rows, 128), **f32)
@@ -360,10 +369,10 @@ class RAFT(nn.Module):
             _conv(x, N, h8, w8, c, ldx, wt, b, kh, kw, 1, pad, act, y, ldy)
 
         for _ in range(iters):
-            _C.call("vspw_corr_lookup", _p(pyr[0]), _p(pyr[1]), _p(pyr[2]), _p(pyr[3]), _p(flow), 2, _p(corr), 324, N,
+            _C.call("vspw_corr_lookup", _p(pyr[0]), _p(pyr[1]), _p(pyr[2]), _p(pyr[3]), _p(flow), 2, _p(corr), ldc, N,
                     h8, w8, _stream())
             # BasicMotionEncoder (update.py:88-96)
-            conv(_p(corr), 324, 324, ub + "encoder.convc1", 1, 1, (0, 0), ACT_RELU, _p(cor1), 256)
+            conv(_p(corr), ldc, ldc, ub + "encoder.convc1", 1, 1, (0, 0), ACT_RELU, _p(cor1), 256)
             conv(_p(cor1), 256, 256, ub + "encoder.convc2", 3, 3, (1, 1), ACT_RELU, _p(CF), 256)
             conv(_p(flow), 2, 2, ub + "encoder.convf1", 7, 7, (3, 3), ACT_RELU, _p(flo1), 128)
             conv(_p(flo1), 128, 128, ub + "encoder.convf2", 3, 3, (1, 1), ACT_RELU, _off(CF, 192), 256)

@@ -94,7 +94,7 @@ def load(check_symbols: bool = False):
         fn.argtypes = argtypes
     if missing:
         raise RuntimeError("libvspw_hip.so does not export: " + ", ".join(missing))
-    if lib.vspw_abi_version() != 6:
+    if lib.vspw_abi_version() != 7:
         raise RuntimeError("libvspw_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -32,7 +32,12 @@ _wino = {"enabled": os.environ.get("VSPW_WINOGRAD", "1") == "1", "min_c": int(os
          "fuse_dgrad": os.environ.get("VSPW_WINO_FUSE_DGRAD", "1") == "1",
          "fuse_max_rows": int(os.environ.get("VSPW_WINO_FUSE_MAXROWS", "512")),
          # the four GEMMs of a transform row in one workgroup (csrc/wino_rows.hip) where the library expects it to win
-         "rows": os.environ.get("VSPW_WINO_ROWS", "1") == "1"}
+         "rows": os.environ.get("VSPW_WINO_ROWS", "1") == "1",
+         # F(3x3,3x3) (csrc/winograd_f3.hip): 25 GEMMs over 3x3 output tiles - 25/81 of the direct multiplications
+         # instead of 36/81, no padded tiles on the 60 / 30 / 15 pixel sub-grids.  VSPW_WINO_F3=0: F(2x2) everywhere;
+         # VSPW_WINO_F3_MINC: smallest channel count (both sides) that takes it
+         "f3": os.environ.get("VSPW_WINO_F3", "1") == "1", "f3_min_c": int(os.environ.get("VSPW_WINO_F3_MINC", "128")),
+         "f3_launches": 0}
 
 
 _strided_pw = {"enabled": os.environ.get("VSPW_STRIDED_PW_DGRAD", "1") == "1"}  # compact GEMM + scatter (conv2d_backward_data)
@@ -55,11 +60,47 @@ def _wino_ok(d):
             and _C.query("vspw_wino_supported", ctypes.byref(d)) == 1)
 
 
+def set_winograd_f3(enabled):
+    prev = _wino["f3"]
+    _wino["f3"] = bool(enabled)
+    return prev
+
+
+def _wino_f3(d):
+    """True when this (Winograd-eligible, see _wino_ok) convolution takes F(3x3,3x3) in all three passes."""
+    return (_wino["f3"] and min(d.c, d.k) >= _wino["f3_min_c"]
+            and _C.query("vspw_wino3_supported", ctypes.byref(d)) == 1)
+
+
+def _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, part=None, what="fwd", u=None,
+                addend=None, act=0):
+    """_wino_conv through F(3x3,3x3): input transform, 25 batched GEMMs, output transform (winograd_f3.hip)."""
+    dev, st = src.device, _stream()
+    T = int(_C.query("vspw_wino3_tiles", ctypes.byref(d)))
+    if u is None:
+        u = _wino3_weights(w, data_gradient)
+    v = torch.empty((25, T, reduce_c), device=dev, dtype=torch.float32)
+    _C.call("vspw_wino3_input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
+    m = torch.empty((25, T, rows), device=dev, dtype=torch.float32)
+    with _Timed("igemm_nt_kernel", 2.0 * 25 * T * rows * reduce_c, _conv_tag(d, what + "-wino3"), _conv_flops(d)):
+        _C.call("vspw_bmm_nt", _p(v), _p(u), _p(m), 25, T, rows, reduce_c, st)
+    z = y_ = mean = invstd = None
+    if front is not None:
+        z, y_, mean, invstd = front
+    _C.call("vspw_wino3_output", ctypes.byref(d), _p(m), rows, _p(bias), _p(dst), _p(z), _p(y_), _p(mean), _p(invstd),
+            _p(part), _p(addend), act, st)
+    _wino["launches"] += 1
+    _wino["f3_launches"] += 1
+    return v
+
+
 def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, part=None, what="fwd", u=None,
                addend=None, act=0, fuse=None, pending=None):
     """dst = conv(src) through U, V, M (see winograd.hip); rows = output channels, reduce_c = channels of src.
     u: transformed weights supplied by the caller (inference: of the BatchNorm-folded weights).
     pending = (y_prev, scale_shift): src has not been written - the input transform evaluates it (see _fwd_apply)."""
+    if pending is None and u is None and _wino_f3(d):
+        return _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front, part, what, None, addend, act)
     dev = src.device
     st = _stream()
     T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
@@ -115,7 +156,7 @@ def _wino_takes_pending(d, pending, wgrad):
     of its own (V kept for the weight gradient; the fused-operand GEMM reads every pixel four times per position) and
     the deferred node has no residual branch."""
     return (_fwd_apply["wino"] and pending[2] is None and _wino["keep_v"] and bool(wgrad) and _wino["wgrad"]
-            and not _wino["fuse_fwd"] and d.c % 4 == 0)
+            and not _wino["fuse_fwd"] and d.c % 4 == 0 and not _wino_f3(d))
 
 
 def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None, wgrad=True):
@@ -135,8 +176,9 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None,
     part = None
     if _wino_ok(d) and (pending is None or _wino_takes_pending(d, pending, wgrad)):
         if want_stats:
-            part = torch.empty((_C.query("vspw_wino_stat_partials", ctypes.byref(d)), 2, k), device=x.device,
-                               dtype=torch.float32)
+            nparts = _C.query("vspw_wino3_stat_partials" if (pending is None and _wino_f3(d)) else "vspw_wino_stat_partials",
+                              ctypes.byref(d))
+            part = torch.empty((nparts, 2, k), device=x.device, dtype=torch.float32)
         # the input transform is kept for this convolution's weight gradient (same V: saves its recomputation there) -
         # only when there will be one: frozen weights / no_grad evaluation take the GEMM that transforms its A operand
         # itself (V, four times the size of x, is then never written)
@@ -284,6 +326,26 @@ _wu_copies = _DerivedWeights(_wu_alloc, _wu_single, "vspw_wino_weights_multi",
                              lambda k, c, kh, kw: _C.query("vspw_wino_weight_tiles", k, c))
 
 
+def _wu3_alloc(w):
+    k, c, kh, kw = w.shape
+    return torch.empty((2, 25, k * c), device=w.device, dtype=torch.float32)
+
+
+def _wu3_single(w, buf, st):
+    k, c, kh, kw = w.shape
+    _C.call("vspw_wino3_weights", _p(w), _p(buf[0]), k, c, 0, st)
+    _C.call("vspw_wino3_weights", _p(w), _p(buf[1]), k, c, 1, st)
+
+
+_wu3_copies = _DerivedWeights(_wu3_alloc, _wu3_single, "vspw_wino3_weights_multi",
+                              lambda k, c, kh, kw: _C.query("vspw_wino_weight_tiles", k, c))
+
+
+def _wino3_weights(w, data_gradient):
+    """U [25][Cout][Cin] (forward) or U' [25][Cin][Cout] (data gradient) of a 3x3 weight, from the per-step cache."""
+    return _wu3_copies.get(w)[1 if data_gradient else 0]
+
+
 def _wino_weights(w, data_gradient):
     """U [16][Cout][Cin] (forward) or U' [16][Cin][Cout] (data gradient) of a 3x3 weight, from the per-step cache."""
     return _wu_copies.get(w)[1 if data_gradient else 0]
@@ -292,6 +354,7 @@ def _wino_weights(w, data_gradient):
 def drop_weight_transpose_cache():
     _wt_copies.clear()
     _wu_copies.clear()
+    _wu3_copies.clear()
 
 
 def conv2d_backward_data(dy, w, d, addend=None, bn_front=None, aff=None):
@@ -307,8 +370,8 @@ def conv2d_backward_data(dy, w, d, addend=None, bn_front=None, aff=None):
         if bn_front is not None:
             z, link = bn_front
             front = (z, link.y, link.mean, link.invstd)
-            part = torch.empty((_C.query("vspw_wino_stat_partials", ctypes.byref(d)), 2, d.c), device=dy.device,
-                               dtype=torch.float32)
+            part = torch.empty((_C.query("vspw_wino3_stat_partials" if _wino_f3(d) else "vspw_wino_stat_partials",
+                                         ctypes.byref(d)), 2, d.c), device=dy.device, dtype=torch.float32)
         _wino_conv(d, dy, w, d.c, d.k, True, None, dx, front=front, part=part, what="dgrad")
         if bn_front is not None:
             link.partials, link.g = part, dx
@@ -389,6 +452,22 @@ def _wino_wgrad(dy, x, d, dw, v=None):
     """dW of a stride-1 3x3 convolution in the Winograd domain (see winograd.hip): 4/9 of the direct multiplications.
     v: the input transform kept by the forward pass (recomputed from x when absent)."""
     dev, st = dy.device, _stream()
+    if _wino_f3(d):
+        T = int(_C.query("vspw_wino3_tiles", ctypes.byref(d)))
+        if v is None or tuple(v.shape) != (25, T, d.c):
+            v = torch.empty((25, T, d.c), device=dev, dtype=torch.float32)
+            _C.call("vspw_wino3_input", ctypes.byref(d), _p(x), d.c, _p(v), st)
+        dm = torch.empty((25, T, d.k), device=dev, dtype=torch.float32)
+        _C.call("vspw_wino3_dy", ctypes.byref(d), _p(dy), d.k, _p(dm), st)
+        du = torch.empty((25, d.k, d.c), device=dev, dtype=torch.float32)
+        nbytes = _C.query("vspw_bmm_tn_workspace", 25, T, d.k, d.c)
+        ws = _ws(nbytes, dev) if nbytes else None
+        with _Timed("igemm_tn_kernel", 2.0 * 25 * T * d.k * d.c, _conv_tag(d, "wgrad-wino3"), _conv_flops(d)):
+            _C.call("vspw_bmm_tn", _p(dm), _p(v), _p(du), 25, T, d.k, d.c, _p(ws), nbytes, st)
+        _C.call("vspw_wino3_dw", _p(du), _p(dw), d.k, d.c, st)
+        _wino["launches"] += 1
+        _wino["f3_launches"] += 1
+        return
     T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
     if v is None or tuple(v.shape) != (16, T, d.c):
         v = torch.empty((16, T, d.c), device=dev, dtype=torch.float32)

@@ -29,7 +29,7 @@ extern "C" {
 #define VSPW_EINVAL (-1)  /* bad argument / geometry / workspace too small */
 #define VSPW_ELAUNCH (-2) /* hipLaunchKernel reported an error */
 
-#define VSPW_ABI_VERSION 6
+#define VSPW_ABI_VERSION 7
 int vspw_abi_version(void);
 /* The hipError_t behind the most recent VSPW_ELAUNCH (0 if none) - for error messages. */
 int vspw_last_hip_error(void);
@@ -229,6 +229,29 @@ int vspw_wino_output_rows(const vspw_conv_desc* d, const float* tp, long long tp
  * [16][Cout][Cin] with V = vspw_wino_input(x); dW = vspw_wino_dw(dU) in the weight layout [Cout][3][3][Cin]. */
 int vspw_wino_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream);
 int vspw_wino_dw(const float* du, float* dw, int k, int c, void* stream);
+
+/* ---------------------------------------------------------------- Winograd F(3x3,3x3) (winograd_f3.hip) --- */
+/* The same convolutions (stride 1, 3x3, pad == dilation; same reference call sites as vspw_wino_*) as 25 batched GEMMs
+ * over 3x3 output tiles / 5x5 input patches (interpolation points 0, 1, -1, 2, inf): 25/81 of the direct multiplications
+ * (F(2x2): 36/81), and 3 divides the 60 / 30 / 15 pixel sub-grid edges of every dilation of the stride-8 stage exactly.
+ *   U = vspw_wino3_weights(w)           [25][rows][reduce]   (G g G^T evaluated in fp64, rounded once)
+ *   V = vspw_wino3_input(x or dy)       [25][T][channels]    T = vspw_wino3_tiles(d)
+ *   M = vspw_bmm_nt(V, U, batch 25)     [25][T][rows]
+ *   y = vspw_wino3_output(M)            arguments and fused epilogues as vspw_wino_output
+ * Weight gradient: dM = vspw_wino3_dy(dY) [25][T][Cout]; dU = vspw_bmm_tn(dM, V, batch 25) [25][Cout][Cin];
+ * dW = vspw_wino3_dw(dU) [Cout][3][3][Cin].  vspw_wino3_weights_multi: entry.wT -> [2][25][k*c], tile0 counted in
+ * vspw_wino_weight_tiles(). */
+size_t vspw_wino3_supported(const vspw_conv_desc* d);
+long long vspw_wino3_tiles(const vspw_conv_desc* d);
+size_t vspw_wino3_stat_partials(const vspw_conv_desc* d);
+int vspw_wino3_weights(const float* w, float* u, int k, int c, int data_gradient, void* stream);
+int vspw_wino3_weights_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream);
+int vspw_wino3_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream);
+int vspw_wino3_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
+                      const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
+                      float* stat_part, const float* addend, int act, void* stream);
+int vspw_wino3_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream);
+int vspw_wino3_dw(const float* du, float* dw, int k, int c, void* stream);
 
 /* ---------------------------------------------------------------- batch norm (bn.hip) ------------- */
 /* Replaces SynchronizedBatchNorm2d.forward = F.batch_norm (models/sync_batchnorm/batchnorm.py:68-98) and its

@@ -155,7 +155,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_C.LIB_PATH)
     missing = [n for n in decls if not hasattr(lib, n)]
     assert not missing, missing
-    assert _C.load(check_symbols=True).vspw_abi_version() == 6
+    assert _C.load(check_symbols=True).vspw_abi_version() == 7
     # workspace queries are pure host functions: exercise the ABI without a GPU
     d = _C.ConvDesc(10, 60, 60, 256, 60, 60, 256, 3, 3, 1, 2, 2, 2)
     assert _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d)) > 0

@@ -75,12 +75,45 @@ def test_conv2d_fwd_bwd(dev, case):
 @pytest.fixture
 def wino_rows_tile(request):
     """Force the row-fused Winograd GEMM (csrc/wino_rows.hip) with the given tile: the library's own dispatch rule only
-    takes it for grids that fill the chip, which unit-test shapes never do."""
-    from cvpr2021_vspw_implement_amd import _C
+    takes it for grids that fill the chip, which unit-test shapes never do.  (F(2x2) only: F(3x3) is switched off.)"""
+    from cvpr2021_vspw_implement_amd import _C, ops
 
-    _C.call("vspw_wino_rows_config", int(request.param))
+    _C.call("vspw_wino_rows_config", max(int(request.param), 0))
+    prev = ops.set_winograd_f3(int(request.param) == -3)  # -3: F(3x3,3x3) instead (no row-fused form)
     yield int(request.param)
+    ops.set_winograd_f3(prev)
     _C.call("vspw_wino_rows_config", 0)
+
+
+@pytest.fixture
+def wino_f3(request):
+    """Tile size of the Winograd path: F(3x3,3x3) (csrc/winograd_f3.hip, True) or F(2x2,3x3) (csrc/winograd.hip)."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    prev = ops.set_winograd_f3(bool(request.param))
+    yield bool(request.param)
+    ops.set_winograd_f3(prev)
+
+
+WINO_CASES = [c for c in CONV_CASES if c[5] == 3 and c[6] == 1 and min(c[1], c[4]) >= 128] + [
+    # exact 3x3 tilings (the bench geometry in small: 30 / 15 pixel sub-grids) and ragged ones
+    (2, 128, 30, 30, 128, 3, 1, 2, 2, False),
+    (1, 256, 15, 30, 128, 3, 1, 4, 4, True),
+    (2, 128, 7, 11, 160, 3, 1, 1, 1, False),
+    (1, 160, 20, 9, 128, 3, 1, 2, 2, False),
+]
+
+
+@pytest.mark.parametrize("wino_f3", [False, True], indirect=True)
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv2d_winograd_tile_sizes(dev, case, wino_f3):
+    """The parity gate of test_conv2d_fwd_bwd (against F.conv2d on the CPU) for both Winograd tile sizes, all three
+    passes; checks that the F(3x3) launches happened when asked for."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    before = ops._wino["f3_launches"]
+    test_conv2d_fwd_bwd(dev, case)
+    assert (ops._wino["f3_launches"] - before) == (3 if wino_f3 else 0)
 
 
 @pytest.mark.parametrize("wino_rows_tile", [12, 31, 22], indirect=True)
@@ -97,7 +130,7 @@ def test_conv2d_winograd_row_fused_form(dev, case, wino_rows_tile):
     test_conv2d_fwd_bwd(dev, case)
 
 
-@pytest.mark.parametrize("wino_rows_tile", [0, 12, 31], indirect=True)
+@pytest.mark.parametrize("wino_rows_tile", [0, 12, 31, -3], indirect=True)
 @pytest.mark.parametrize("dil,h,w", [(1, 12, 13), (2, 14, 14), (4, 15, 15)])
 def test_winograd_path_equals_direct_path_in_a_fused_chain(dev, dil, h, w, wino_rows_tile):
     """1x1 conv+BN+ReLU -> 3x3 conv+BN+ReLU (fuse_input: the 3x3 data gradient carries the first node's BatchNorm-backward
@@ -275,8 +308,9 @@ def test_block_output_evaluated_by_the_next_conv1(dev, n, cm, c, h, w, k, fused,
         _close(got.grad, want.grad, 5e-4, what)
 
 
+@pytest.mark.parametrize("wino_f3", [False], indirect=True)  # the deferred apply exists for the F(2x2) input transform only
 @pytest.mark.parametrize("dil,h,w,c1", [(2, 13, 14, 128), (1, 9, 11, 256), (4, 15, 15, 128)])
-def test_conv1_apply_evaluated_by_the_winograd_input_transform(dev, dil, h, w, c1):
+def test_conv1_apply_evaluated_by_the_winograd_input_transform(dev, dil, h, w, c1, wino_f3):
     """relu(bn1(conv1(x))) left to conv2's Winograd input transform (models/resnet.py:76-79, vspw_wino_input_apply): the
     deferred and the materialised evaluation are the same float32 expression - every output and gradient BIT-identical -
     and both match autograd on the plain composition; ragged dilation sub-grids, padding taps stay zero."""

@@ -184,3 +184,98 @@ def test_two_rank_training_driver(dev, tree, tmp_path):
     l0, l1 = (np.load(os.path.join(save, "rank%d_loss.npy" % k)) for k in (0, 1))
     assert len(l0) == len(l1) == 2 and np.all(np.isfinite(l0)) and np.all(np.isfinite(l1))
     assert not np.array_equal(l0, l1)                       # each rank trained on its own shard
+
+
+@pytest.mark.parametrize("hip_graph", [False, True])
+@pytest.mark.parametrize("kind", ["clip_psp", "clip_ocr"])
+def test_tcb_training_trajectory_follows_the_reference(dev, tmp_path, kind, hip_graph):
+    """Twenty optimisation steps of the TCB heads through THIS repo's train_clip2.train (eager and --hip_graph) against the
+    reference's own train() (train_clip2.py:26-124 with its create_optimizers / adjust_learning_rate: four SGD groups,
+    head at 10x the encoder rate, duplicate parameter listings with PyTorch 1.3.1's in-place weight decay, poly schedule,
+    BatchNorm running statistics over steps) run in the build container in float64, float32 and as a six-member float32
+    ensemble whose first image carries a one-ulp perturbation (tests/golden/make_golden_trajectory.py ->
+    tcb_train_trajectory_<kind>.npz; R50, T = 3, B = 2, 97 x 97, well-conditioned "damped" weights).
+    Gate: at EVERY step |loss - float64| within 2 x the ensemble's own largest deviation at that step (floor 3e-6
+    relative) - i.e. the HIP trajectory is indistinguishable from a float32 realisation of the reference's loop.  The gate
+    has teeth: the same loop with torch 2.10's out-of-place weight decay ("n32" in the fixture) leaves the envelope at
+    step 1 by two orders of magnitude.  Final parameter norms per SGD group, momentum norms and the running statistics
+    of five BatchNorm layers are held to the same ensemble yardstick."""
+    import cvpr2021_vspw_implement_amd.train_clip2 as T
+    from helpers import K, golden, load_det, zero_dropout
+    from oracle.det_init import damp_residual_gammas, det_input, det_labels
+
+    fx = golden("tcb_train_trajectory_" + kind)
+    steps, num_epoch, Tn, B, S = (int(v) for v in fx["meta"])
+    tag = "tcb_train_trajectory_" + kind
+    argv = ["--method", kind, "--dataroot", str(tmp_path), "--saveroot", str(tmp_path / "t"), "--batchsize", str(B),
+            "--cropsize", str(S), "--clip_num", str(Tn), "--dilation2", ",".join(str(3 * (i + 1)) for i in range(Tn - 1)),
+            "--totalepoch", str(num_epoch), "--lr", repr(float(fx["lr"])), "--workers", "0", "--gpus", "0"] + \
+           (["--hip_graph"] if hip_graph else [])
+    args = T.build_parser().parse_args(argv)
+    cfg = _cfg("ppm_deepsup_clip")  # (the per-frame decoder build_module constructs is unused by both TCB heads)
+    here = os.path.dirname(os.path.abspath(T.__file__))
+    args.cfg = os.path.join(here, "config", "vsp-resnet101dilated-ppm_deepsup_clip.yaml")
+    T.prepare(args, cfg)
+    cfg.MODEL.arch_encoder = "resnet50dilated"
+    cfg.TRAIN.num_epoch, cfg.TRAIN.fix_bn, cfg.TRAIN.weight_decay = num_epoch, False, 1e-4
+    mod = T.build_module(cfg, args, K, training=True)
+    load_det(mod)
+    sd = mod.state_dict()
+    assert damp_residual_gammas(sd)
+    mod.load_state_dict(sd)
+    zero_dropout(mod)
+    mod.to(dev)
+    opt = T.create_optimizers(mod, cfg, args)
+    assert [sum(g["mult"]) for g in opt.param_groups] == [int(v) for v in fx["group_sizes"]]
+    assert [len(g["params"]) for g in opt.param_groups] == [int(v) for v in fx["group_unique"]]
+    batches = []
+    for it in range(steps):
+        imgs = [torch.from_numpy(det_input("%s:img:%d:%d" % (tag, it, t), (B, 3, S, S))).to(dev) for t in range(Tn)]
+        labs = [torch.from_numpy(det_labels("%s:lab:%d:%d" % (tag, it, t), (B, 1, S, S), K)).to(dev) for t in range(Tn)]
+        batches.append((imgs, labs))
+    hist = {"train": {"epoch": [], "loss": [], "acc": []}}
+    T.train(mod, batches, opt, hist, 1, cfg, args, transform=None, log=lambda *a: None)
+    torch.cuda.synchronize()
+    assert (getattr(args, "_graphed_step", None) is not None) == hip_graph
+    members = ("f32", "p0", "p1", "p2", "p3", "p4", "p5")
+    l64 = fx["f64:loss"]
+    ens = np.stack([np.abs(fx[m + ":loss"] - l64) for m in members]).max(0)
+    err = np.abs(np.array(hist["train"]["loss"]) - l64)
+    print(kind, "graph" if hip_graph else "eager", "|hip - ref64| / ensemble envelope per step:",
+          " ".join("%.2f" % (e / max(g, 1e-12)) for e, g in zip(err, ens)))
+    print("   |hip - ref64|", " ".join("%.1e" % e for e in err))
+    print("   envelope     ", " ".join("%.1e" % e for e in ens))
+    print("   torch-2.10-SGD run |n32 - ref64|", " ".join("%.1e" % e for e in np.abs(fx["n32:loss"] - l64)))
+    for t in range(steps):
+        gate = max(3e-6 * abs(l64[t]), 2.0 * ens[t])
+        assert err[t] <= gate, (t, hist["train"]["loss"][t], float(l64[t]), float(err[t]), gate)
+    assert err[0] <= 3e-6 * abs(l64[0])  # before any update: the forward pass alone
+    # the yardstick has teeth: the out-of-place-decay SGD would fail this very gate early on
+    assert np.abs(fx["n32:loss"] - l64)[1] > 5.0 * max(3e-6 * abs(l64[1]), 2.0 * ens[1])
+    acc = np.array(hist["train"]["acc"])
+    assert np.abs(acc - fx["f64:acc"]).max() <= max(2.0 * np.stack([np.abs(fx[m + ":acc"] - fx["f64:acc"]) for m in members]).max(), 2e-4)
+
+    def yard(key, got, floor):
+        ref = fx["f64:" + key]
+        scale = np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max())
+        gap = np.stack([np.abs(fx[m + ":" + key] - ref) for m in members]).max(0) / scale
+        e = np.abs(got - ref) / scale
+        assert np.median(e) <= max(3.0 * np.median(gap), floor), (key, float(np.median(e)), float(np.median(gap)))
+        assert e.max() <= max(3.0 * gap.max(), 30 * floor), (key, float(e.max()), float(gap.max()), int(e.argmax()))
+
+    names = [str(n) for n in fx["param_names"]]
+    got = dict((k, float(p.detach().double().norm())) for k, p in mod.named_parameters())
+    yard("param_norms", np.array([got[k] for k in names]), 1e-6)
+    yard("group_norms", np.array([float(torch.sqrt(sum((p.detach().double() ** 2).sum() for p in g["params"])))
+                                  for g in opt.param_groups]), 1e-6)
+    seen, mom = set(), []
+    for g in opt.param_groups:  # first-occurrence order over the groups, as the fixture lists them
+        for p in g["params"]:
+            if id(p) not in seen:
+                seen.add(id(p))
+                mom.append(float(opt.state[p]["momentum_buffer"].double().norm()))
+    yard("momentum_norms", np.array(mom), 1e-5)
+    state = mod.state_dict()
+    for bn in (str(b) for b in fx["bn_layers"]):
+        for what, key in (("rm", "running_mean"), ("rv", "running_var")):
+            yard("%s:%s" % (what, bn), state["%s.%s" % (bn, key)].double().cpu().numpy(), 1e-6)

@@ -390,6 +390,7 @@ def main():
     bn_events, red_events = [], {}
     clock_probe = (ctypes.c_ulonglong * 2)()
     _C.call("vspw_debug_nt_clock", None, 1)  # zero the shader-cycle / wall-clock sums of the GEMM launches (device idle here)
+    _C.call("vspw_debug_nt_clock_enable", 1)  # the probe is off outside this timed region
     t0 = time.perf_counter()
     for i in range(args.steps):
         ev = i in timed_steps
@@ -408,6 +409,7 @@ def main():
     model.reducer.timer = None
     wd.phase("max-over-ranks timing")
     _C.call("vspw_debug_nt_clock", clock_probe, 0)
+    _C.call("vspw_debug_nt_clock_enable", 0)
     # shader clock the chip sustained inside the forward / data-gradient GEMM launches of the timed steps (workgroup 0 of
     # every launch: s_memtime cycles / 100 MHz wall ticks); the fp32 MFMA peak is quoted at 2.4 GHz
     sustained_ghz = (clock_probe[0] / (clock_probe[1] * 10.0)) if clock_probe[1] else None

@@ -10,7 +10,7 @@ from . import _C
 from ._C import ConvDesc
 from ._opbase import (_Timed, _conv_desc, _conv_flops, _conv_tag, _p, _require_gpu, _stream, _ws, empty_nhwc, is_nhwc,
                       to_nhwc)
-from ._ops_conv import (_fwd_apply, _wino, _wino_conv, _wino_ok, _wino_takes_pending, _wt_cache, colsum,
+from ._ops_conv import (_fwd_apply, _wino, _wino3_conv, _wino_conv, _wino_f3, _wino_ok, _wino_takes_pending, _wt_cache, colsum,
                         conv2d_backward_data, conv2d_backward_weight, conv2d_forward)
 
 # --------------------------------------------------------------------------------------------------- batch norm
@@ -258,8 +258,14 @@ def _conv_bn_folded(x, w, cbias, gamma, beta, running_mean, running_var, residua
         residual = to_nhwc(residual)
         if tuple(residual.shape) != tuple(z.shape):
             raise RuntimeError("conv_bn_act: residual %s vs output %s" % (tuple(residual.shape), tuple(z.shape)))
-    if _wino_ok(d):  # stride-1 3x3: Winograd on the folded weights (their transform is cached with them)
-        if ent[3] is None:
+    if _wino_ok(d) and _wino_f3(d):  # stride-1 3x3: Winograd F(3x3,3x3) on the folded weights (transform cached with them)
+        if ent[3] is None or ent[3].shape[0] != 25:
+            ent[3] = torch.empty((25, k, c), device=x.device, dtype=torch.float32)
+            _C.call("vspw_wino3_weights", _p(wf), _p(ent[3]), k, c, 0, st)
+        _wino3_conv(d, x, None, k, c, False, bf, z, what="fwd-fold", u=ent[3], addend=residual, act=1 if relu else 0)
+        return z
+    if _wino_ok(d):  # ... F(2x2,3x3) (VSPW_WINO_F3=0)
+        if ent[3] is None or ent[3].shape[0] != 16:
             ent[3] = torch.empty((16, k, c), device=x.device, dtype=torch.float32)
             _C.call("vspw_wino_weights", _p(wf), _p(ent[3]), k, c, 0, st)
         _wino_conv(d, x, None, k, c, False, bf, z, what="fwd-fold", u=ent[3], addend=residual, act=1 if relu else 0,

@@ -51,6 +51,11 @@ def set_accum_chunk(k):
     return prev
 
 
+def accum_chunk_supported():
+    """The two-level accumulation variants exist in diagnostic builds only (-DVSPW_WITH_ACCUM_CHUNK)."""
+    return int(_C.query("vspw_accum_chunk_compiled")) == 1
+
+
 def set_winograd(enabled):
     _wino["enabled"] = bool(enabled)
 

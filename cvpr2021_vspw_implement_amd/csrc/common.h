@@ -29,8 +29,8 @@ static inline int vspw_cdiv(long long a, long long b) { return (int)((a + b - 1)
 static inline int vspw_stream_grid(long long work_items, int block) {
     static const long long cap = getenv("VSPW_STREAM_BLOCKS") ? atoll(getenv("VSPW_STREAM_BLOCKS")) : 256 * 4;  // (env: experiments)
     long long g = (work_items + block - 1) / block;
+    if (g > cap && cap >= 1) g = cap;  // (a zero / negative / unparsable VSPW_STREAM_BLOCKS is ignored)
     if (g < 1) g = 1;
-    if (g > cap) g = cap;
     return (int)g;
 }
 

@@ -395,12 +395,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(IgemmNT pin) {
 #define NT_PROGRESS_PRIO(kt, nk)
 #endif
 
-#define NT_V2_BOUNDS(WM, WN, MODE, NBUF, TAPS, AFF) \
-    ((WM * WN <= 3 && NBUF == 1 && MODE != 2 && TAPS == 0) ? 4 : ((NBUF == 1 && !(AFF && WM * WN > 3)) ? 3 : 2))
+// (the tap-outer gather variants - MODE 0 / 1, TAPS 0 - used to ask for 4 workgroups per CU: 128 registers, 3-10 of them
+// spilled to scratch; at 3 they fit)
+#define NT_V2_BOUNDS(WM, WN, MODE, NBUF, TAPS, AFF) ((NBUF == 1 && !(AFF && WM * WN > 3)) ? 3 : 2)
 
 // One output tile.  vb_in = tile index of this workgroup (already XCD-remapped), batch_idx = batch of a batched GEMM,
 // stamp_slot = slot of the diagnostic stamps.  Called once per workgroup by igemm_nt_v2_kernel and in a loop by the
-// persistent variant below.
+// kernel below.
 template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS, int AFF, int CHUNK = 0, int FOLD = 0>
 __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, int batch_idx, int stamp_slot) {
     IgemmNT p = pin;
@@ -1120,10 +1121,14 @@ __device__ __forceinline__ void igemm_nt_v2_body(const IgemmNT& pin, int vb_in, 
 // (tools/diag/nt_clock{,_idle}.py, profiles/r05_nt_clock.log): 329-354 k cycles every time, at 1.87 ... 2.40 GHz depending on
 // operand values (zero-filled: 2.34 GHz, random: 1.9) and on what ran in the milliseconds before = 109 ... 131 TFLOP/s from
 // the same code.  The 157.3 TFLOP/s peak is quoted at 2.4 GHz.
+// OFF unless armed (vspw_debug_nt_clock_enable): an unarmed launch pays one scalar load in one wave.  One start stamp per
+// device: arm it only while the NT launches of ONE stream run one after the other (bench.py's timed region does; launches
+// that overlap on several streams would mix their stamps).
 __device__ unsigned long long vspw_nt_clock_probe[4];  // [0] ticks start, [1] wall start (scratch); [2] sum ticks, [3] sum wall
+__device__ int vspw_nt_clock_armed = 0;
 template <int WGM, int WM, int WN, int MODE, int NBUF, int TAPS = 0, int AFF = 0, int CHUNK = 0, int FOLD = 0>
 __global__ __launch_bounds__(256, NT_V2_BOUNDS(WM, WN, MODE, NBUF, TAPS, AFF)) void igemm_nt_v2_kernel(IgemmNT pin) {
-    const bool probe = (blockIdx.x | blockIdx.y | threadIdx.x) == 0;
+    const bool probe = (blockIdx.x | blockIdx.y | threadIdx.x) == 0 && vspw_nt_clock_armed != 0;
     if (probe) {
         vspw_nt_clock_probe[0] = __builtin_readcyclecounter();
         vspw_nt_clock_probe[1] = wall_clock64();
@@ -1151,27 +1156,12 @@ extern "C" int vspw_debug_nt_clock(unsigned long long* out, int reset) {
     return VSPW_OK;
 }
 
-// Persistent variant (short-K pointwise GEMMs): gridDim.x = resident workgroup slots (a multiple of 8), each workgroup
-// walks the tiles of its XCD's contiguous range with stride slots / 8.  Measured with per-workgroup stamps on the
-// Winograd 16 x 9000 x 256 x 256 GEMM (tools/diag/nt_occupancy.py): a workgroup lives 90 k cycles and its CU slot then
-// stays EMPTY for 2-10 k cycles until the dispatcher has placed the successor (37 KB LDS, 4 x 166 registers) - average
-// residency 2.6 of 3 workgroups per CU.  A workgroup that fetches its next tile itself has no such gap - but see
-// launch_nt_persist: it did not pay (experiment, VSPW_PERSIST=1).
-template <int WGM, int WM, int WN, int AFF>
-__global__ __launch_bounds__(256, NT_V2_BOUNDS(WM, WN, 2, 1, 0, AFF)) void igemm_nt_v2_persist_kernel(IgemmNT pin, int total,
-                                                                                                    int per_batch) {
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3, nq = gridDim.x >> 3;
-    const int per = total >> 3, rem = total & 7;
-    const int base = (xcd < rem) ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per;
-    const int cnt = per + (xcd < rem ? 1 : 0);
-    for (int j = q; j < cnt; j += nq) {
-        const int lin = base + j;
-        if (AFF == 4)
-            igemm_nt_v2_body<WGM, WM, WN, 2, 1, 0, AFF>(pin, lin, 0, lin);
-        else
-            igemm_nt_v2_body<WGM, WM, WN, 2, 1, 0, AFF>(pin, lin % per_batch, lin / per_batch, lin);
-        __syncthreads();  // the next tile's operand stores must not overtake this tile's last LDS reads
-    }
+// Arm (on != 0) / disarm the probe above.  Synchronises the device.
+extern "C" int vspw_debug_nt_clock_enable(int on) {
+    const int v = on ? 1 : 0;
+    if (hipDeviceSynchronize() != hipSuccess) return VSPW_ELAUNCH;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(vspw_nt_clock_armed), &v, sizeof(v)) != hipSuccess) return VSPW_ELAUNCH;
+    return VSPW_OK;
 }
 
 #ifdef VSPW_NT_TIMING
@@ -1213,32 +1203,6 @@ static int nt_pick_tile(long long m, int nout, int batch = 1) {
 
 static int nt_tile_rows(int cfg) { return (cfg == 22 || cfg == 21) ? 128 : (cfg == 31 ? 96 : 64); }
 
-// Persistent launch of a pointwise GEMM (igemm_nt_v2_persist_kernel): grid = the workgroup slots of the chip.
-template <int WGM, int WM, int WN, int AFF>
-static bool launch_nt_persist(const IgemmNT& p, int tm, int tn, int fold, hipStream_t st) {
-    // OFF by default: measured (tools/diag/gemm_time.py, bench step) the walk gains nothing - Winograd 256 GEMM 193.6 ->
-    // 191.8 us, pointwise 256 -> 1024 149 -> 154 us, 512 -> 2048 547 -> 569 us, step 84.6 -> 86.5 ms: the static tile
-    // assignment loses to the dispatcher's dynamic one what the missing gaps win, and the loop costs 14-80 SGPR spills
-    static const int enabled = getenv("VSPW_PERSIST") ? atoi(getenv("VSPW_PERSIST")) : 0;
-    static const int max_k = getenv("VSPW_PERSIST_MAXK") ? atoi(getenv("VSPW_PERSIST_MAXK")) : 1024;
-    if (!enabled || p.kdim > max_k) return false;
-    static int slots = 0;
-    if (slots == 0) {
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, igemm_nt_v2_persist_kernel<WGM, WM, WN, AFF>, 256, 0) !=
-                hipSuccess || hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
-            per_cu = 0;
-        slots = per_cu > 0 ? (per_cu * prop.multiProcessorCount) / 8 * 8 : -1;
-    }
-    const int per_batch = vspw_cdiv(p.m, tm) * vspw_cdiv(p.nout, tn);
-    const long long total = (long long)per_batch * fold;
-    if (slots <= 0 || total <= slots || total > 0x7fffffffLL) return false;  // fewer tiles than slots: nothing to walk
-    hipLaunchKernelGGL((igemm_nt_v2_persist_kernel<WGM, WM, WN, AFF>), dim3(slots), dim3(256), 0, st, p, (int)total,
-                       AFF == 4 ? (int)total : per_batch);
-    return true;
-}
-
 static int nt_tap_inner() {
     static const int v = getenv("VSPW_TAP_INNER") ? atoi(getenv("VSPW_TAP_INNER")) : 1;
     return v;
@@ -1263,16 +1227,32 @@ static bool nt_folds(const IgemmNT& p) {
 // chains of 256 halve the rounding error of a K >= 1024 GEMM but move the end-to-end parity figures by < 0.1x while
 // costing 2.8 ms per step; the excess sat in the direct 3x3 kernels, see FOLD).  VSPW_ACCUM_CHUNK / vspw_set_accum_chunk.
 static int g_accum_chunk = -1;
+// The variants are compiled only with -DVSPW_WITH_ACCUM_CHUNK (tools/diag/build_variant.py; 29-45 SGPR spills each, +2.8 ms
+// per step when on): the shipped library accepts 0 only.
 static int accum_chunk() {
+#ifdef VSPW_WITH_ACCUM_CHUNK
     if (g_accum_chunk < 0) g_accum_chunk = getenv("VSPW_ACCUM_CHUNK") ? atoi(getenv("VSPW_ACCUM_CHUNK")) / BK * BK : 0;
     return g_accum_chunk;
+#else
+    return 0;
+#endif
 }
 extern "C" int vspw_set_accum_chunk(int k) {
     if (k < 0 || k % BK != 0) return VSPW_EINVAL;
+#ifndef VSPW_WITH_ACCUM_CHUNK
+    if (k != 0) return VSPW_EINVAL;  // not compiled in
+#endif
     g_accum_chunk = k;
     return VSPW_OK;
 }
 extern "C" int vspw_get_accum_chunk(void) { return accum_chunk(); }
+extern "C" int vspw_accum_chunk_compiled(void) {
+#ifdef VSPW_WITH_ACCUM_CHUNK
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 // pointwise (MODE 2) launch of one A-operand flavour (AFF 0-3), with / without two-level accumulation
 template <int A, int CH>
@@ -1283,7 +1263,6 @@ static void launch_nt_pw(const IgemmNT& p, int cfg, hipStream_t st) {
         // single-buffer variant (3 workgroups/CU); long ones gain 2-5 % from the second buffer (one barrier per tile)
         static const int nbuf1_max_k = getenv("VSPW_NBUF1_MAXK") ? atoi(getenv("VSPW_NBUF1_MAXK")) : 1024;
         if constexpr (A == 0) {
-            if (!CH && p.kdim <= nbuf1_max_k && launch_nt_persist<2, 2, 2, 0>(p, 128, 128, p.batch, st)) return;
             if (p.kdim > nbuf1_max_k) {
                 hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, 2, 2, 0, 0, CH>), dim3(tiles, p.batch), dim3(256), 0, st, p);
                 return;
@@ -1291,9 +1270,6 @@ static void launch_nt_pw(const IgemmNT& p, int cfg, hipStream_t st) {
         }
         hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, 2, 1, 0, A, CH>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     } else if (cfg == 31) {
-        if constexpr (A == 0) {
-            if (!CH && launch_nt_persist<1, 3, 1, 0>(p, 96, 128, p.batch, st)) return;
-        }
         int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
         hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, 2, 1, 0, A, CH>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     } else if (cfg == 12) {
@@ -1315,7 +1291,7 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
             if (cfg == 12) {
                 int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
                 hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, 2, 1, 0, 4>), dim3(tiles * 16), dim3(256), 0, st, p);
-            } else if (!launch_nt_persist<1, 3, 1, 4>(p, 96, 128, 16, st)) {
+            } else {
                 int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
                 hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, 2, 1, 0, 4>), dim3(tiles * 16), dim3(256), 0, st, p);
             }
@@ -1324,16 +1300,22 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
         // A operand: 2 = fused forward apply of the producing node (A operand + z), 3 = ... of a node without a residual
         // branch, 1 = affine (fused BatchNorm-backward apply), 0 = plain
         const int aff = (p.src2 != nullptr && p.zout != nullptr) ? 2 : (p.zout != nullptr ? 3 : (p.src2 != nullptr ? 1 : 0));
-        const bool ch = p.chunk_tiles > 0;
-        switch (aff * 2 + (ch ? 1 : 0)) {
+#ifdef VSPW_WITH_ACCUM_CHUNK  // two-level accumulation variants: diagnostic builds only (tools/diag/build_variant.py)
+        if (p.chunk_tiles > 0) {
+            switch (aff) {
+                case 0: launch_nt_pw<0, 1>(p, cfg, st); break;
+                case 1: launch_nt_pw<1, 1>(p, cfg, st); break;
+                case 2: launch_nt_pw<2, 1>(p, cfg, st); break;
+                default: launch_nt_pw<3, 1>(p, cfg, st); break;
+            }
+            return;
+        }
+#endif
+        switch (aff) {
             case 0: launch_nt_pw<0, 0>(p, cfg, st); break;
-            case 1: launch_nt_pw<0, 1>(p, cfg, st); break;
-            case 2: launch_nt_pw<1, 0>(p, cfg, st); break;
-            case 3: launch_nt_pw<1, 1>(p, cfg, st); break;
-            case 4: launch_nt_pw<2, 0>(p, cfg, st); break;
-            case 5: launch_nt_pw<2, 1>(p, cfg, st); break;
-            case 6: launch_nt_pw<3, 0>(p, cfg, st); break;
-            default: launch_nt_pw<3, 1>(p, cfg, st); break;
+            case 1: launch_nt_pw<1, 0>(p, cfg, st); break;
+            case 2: launch_nt_pw<2, 0>(p, cfg, st); break;
+            default: launch_nt_pw<3, 0>(p, cfg, st); break;
         }
         return;
     }
@@ -1344,18 +1326,18 @@ static void launch_nt_v2(const IgemmNT& p, int cfg, hipStream_t st) {
                 hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, MODE, 1, 9, 0, 0, 3>), dim3(tiles, p.batch), dim3(256), 0, st, p);
                 return;
             }
-            if (cfg == 22) {
+            // (fallback forms - stride-1 3x3s with >= 128 channels take Winograd, narrower ones the folded tile above: the
+            // 128x64 tile and the data gradient's 128x128 tile, whose tap state spilled 28-34 SGPRs, run on 64x64 / 96x128)
+            // (nt_decide never hands 21, nor 22 to the data gradient, to this branch)
+            if (cfg == 22 && MODE == 0) {
                 int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
-                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, MODE, 1, 9>), dim3(tiles, p.batch), dim3(256), 0, st, p);
+                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 2, 0, 1, 9>), dim3(tiles, p.batch), dim3(256), 0, st, p);
             } else if (cfg == 31) {
                 int tiles = vspw_cdiv(p.m, 96) * vspw_cdiv(p.nout, 128);
                 hipLaunchKernelGGL((igemm_nt_v2_kernel<1, 3, 1, MODE, 1, 9>), dim3(tiles, p.batch), dim3(256), 0, st, p);
             } else if (cfg == 12) {
                 int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
                 hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 2, MODE, 1, 9>), dim3(tiles, p.batch), dim3(256), 0, st, p);
-            } else if (cfg == 21) {
-                int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 64);
-                hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 2, 1, MODE, 1, 9>), dim3(tiles, p.batch), dim3(256), 0, st, p);
             } else {
                 int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 64);
                 hipLaunchKernelGGL((igemm_nt_v2_kernel<2, 1, 1, MODE, 1, 9>), dim3(tiles, p.batch), dim3(256), 0, st, p);
@@ -1403,8 +1385,15 @@ static int nt_decide(const IgemmNT& p, bool& v2) {
     // byte offsets (incl. the scalar channel / k base) must stay below the 2 GiB out-of-range marker of the buffer loads
     v2 = p.vec && p.c % BK == 0 && span < (1LL << 28) && (long long)p.kdim < (1LL << 21) &&
          true;  // forward (any stride) and data gradient (any stride: inexact taps are masked per tap)
-    if (!v2 && cfg == 31) cfg = 12;  // the generic kernel has no 96-row instantiation
+    if (!v2 && (cfg == 31 || cfg == 22)) cfg = 12;  // the generic kernel has no 96-row instantiation (and its 128x128 one spilled)
     if (v2 && nt_folds(p)) cfg = 11;  // direct 3x3 with folded chains: see nt_folds
+    // fallback direct 3x3 forms of the v2 kernel (tap-inner K order, no folded chains): the 128x64 tile and the data
+    // gradient's 128x128 tile kept their tap state in 28-34 spilled SGPRs - they run on 64x64 / 96x128 instead.  (The
+    // statistics-partials counts follow this function: one place decides.)
+    if (v2 && nt_tap_inner() && p.kh == 3 && p.kw == 3) {
+        if (cfg == 21) cfg = 11;
+        if (cfg == 22 && p.mode != 0) cfg = 31;
+    }
     return cfg;
 }
 
@@ -1424,10 +1413,7 @@ static int launch_igemm_nt(const IgemmNT& pin, hipStream_t st) {
             launch_nt_v2<1>(p, cfg, st);
         return vspw_launch_status();
     }
-    if (cfg == 22) {
-        int tiles = vspw_cdiv(p.m, 128) * vspw_cdiv(p.nout, 128);
-        hipLaunchKernelGGL((igemm_nt_kernel<2, 2>), dim3(tiles, p.batch), dim3(256), 0, st, p);
-    } else if (cfg == 12) {
+    if (cfg == 12) {
         int tiles = vspw_cdiv(p.m, 64) * vspw_cdiv(p.nout, 128);
         hipLaunchKernelGGL((igemm_nt_kernel<1, 2>), dim3(tiles, p.batch), dim3(256), 0, st, p);
     } else if (cfg == 21) {

@@ -425,6 +425,9 @@ extern "C" int vspw_conv2d_thin(const vspw_conv_desc* d, const float* x, long lo
                                 int act, float* y, long long ldy, void* stream) {
     const int kind = vspw_conv2d_thin_supported(d, ldx, ldy);
     if (!kind || !x || !w || !y || ldx < d->c || ldy < d->k || act < 0 || act > 3) return VSPW_EINVAL;
+    // the kernel reads x and w as float4: a channel slot that starts at an odd multiple of 4 bytes is the caller's cue to
+    // take vspw_conv2d_fwd_ex instead (models/raft.py checks the same condition before it calls)
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) & 15) return VSPW_EINVAL;
     const long long P = (long long)d->n * d->h * d->w;
     hipStream_t st = vspw_stream(stream);
     const int ppw = 4;  // pixels per wave: the weight registers are loaded once per wave

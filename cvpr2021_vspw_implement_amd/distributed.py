@@ -236,14 +236,52 @@ class GradReducer:
             self.timer.setdefault("wait", []).append((w0, w1))
 
 
+def _world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def all_agree(flag, device=None):
+    """True on every rank iff `flag` is true on every rank (one tiny MIN all-reduce + a host read; every rank must
+    call it).  The drivers use it before choosing between a captured hipGraph and the eager step: a rank that replays a
+    graph while a peer runs the step launch by launch would issue a different sequence of collectives."""
+    if _world() <= 1:
+        return bool(flag)
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device())
+                                             if (torch.cuda.is_available() and dist.get_backend() != "gloo") else "cpu")
+    t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=dev)
+    all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()) == 1)
+
+
+class PeerAbort(RuntimeError):
+    """Raised by step_guard on the ranks whose own step was fine when another rank aborted."""
+
+
 def step_guard(module, loss_value):
     """Called by the drivers where they read the loss (a device sync they pay anyway): a peer statistics exchange that
     timed out has overwritten BatchNorm totals with NaN (exchange.hip) - raise instead of training on, and never let a
-    non-finite loss reach the running statistics / a checkpoint silently."""
-    if hasattr(module, "check_exchange"):
-        module.check_exchange()
-    if not math.isfinite(loss_value):
-        raise FloatingPointError("non-finite training loss (%r): aborting before it is written into a checkpoint" % (loss_value,))
+    non-finite loss reach the running statistics / a checkpoint silently.
+    With more than one rank the decision is COLLECTIVE: the loss is per rank, so a rank that raised alone would leave its
+    peers blocked in the next step's first collective (or in checkpoint_barrier) until the process-group timeout.  Every
+    rank contributes a "my step is bad" flag to one MAX all-reduce here; the rank(s) with the local problem raise their
+    own error, every other rank raises PeerAbort - all of them in the same step."""
+    err = None
+    try:
+        if hasattr(module, "check_exchange"):
+            module.check_exchange()
+    except (RuntimeError, ValueError) as e:
+        err = e
+    if err is None and not math.isfinite(loss_value):
+        err = FloatingPointError("non-finite training loss (%r): aborting before it is written into a checkpoint" % (loss_value,))
+    if _world() > 1 and getattr(module, "reducer", None) is not None and module.reducer.active:
+        dev = next(module.parameters()).device
+        t = torch.tensor([0 if err is None else 1], dtype=torch.int64, device=dev)
+        all_reduce(t, op=dist.ReduceOp.MAX)
+        if err is None and int(t.item()) != 0:
+            err = PeerAbort("another rank aborted this training step (non-finite loss, uneven SyncBN batch or a timed-out "
+                            "peer exchange there): stopping here too instead of waiting in the next collective")
+    if err is not None:
+        raise err
 
 
 def checkpoint_barrier():
@@ -269,7 +307,8 @@ class DataParallelOverRCCL(torch.nn.Module):
         # SyncBN statistics: hipIpc peer exchange (peer_exchange.py) when every rank of the group could set it up and
         # its self-test passed everywhere, torch.distributed all-reduces otherwise (VSPW_SYNCBN_PEER=0: always)
         self._sync_bn = bool(sync_bn)
-        self._batch_sig = None
+        self._sig_cache, self._sig_pending = {}, None
+        self._sig_work = self._sig_host = self._sig_stream = None
         self.exchange = None
         self.exchange_why = "not requested"  # why SyncBN statistics go through torch.distributed instead (bench.py reports it)
         if sync_bn and self.reducer.active and torch.cuda.is_available() and os.environ.get("VSPW_SYNCBN_PEER", "1") == "1":
@@ -285,15 +324,19 @@ class DataParallelOverRCCL(torch.nn.Module):
         self._check_equal_batches(a, k)
         return self.module(*a, **k)
 
-    def _check_equal_batches(self, a, k):
-        """SyncBN totals are finalised with count = local rows x ranks (the fused exchange + finalise kernel carries
-        sums only), which is the reference's sum over the replicas' real sizes (models/sync_batchnorm/batchnorm.py:
-        110-131) only when every rank holds the same batch shape - what the drivers' drop_last guarantees.  A caller
-        that feeds uneven batches gets an error instead of silently biased statistics: the shapes are compared across
-        the ranks whenever the local signature changes (one small collective at the first step)."""
-        if not (self.training and self.reducer.active and self._sync_bn and dist.is_initialized() and dist.get_world_size() > 1):
-            return
-
+    # ---- SyncBN needs the same batch shape on every rank -----------------------------------------------------------
+    # SyncBN totals are finalised with count = local rows x ranks (the fused exchange + finalise kernel carries sums
+    # only), which is the reference's sum over the replicas' real sizes (models/sync_batchnorm/batchnorm.py:110-131) only
+    # when every rank holds the same batch shape - what the drivers' drop_last guarantees.  A caller that feeds uneven
+    # batches gets a ValueError ON EVERY RANK instead of silently biased statistics.  The comparison is symmetric and
+    # unconditional: EVERY rank contributes a 62-bit hash of its shape signature to one MAX all-reduce of (h, -h) on
+    # EVERY training-mode forward (a rank whose batch changes mid-run - a short last batch - is caught although its
+    # peers' signatures did not change; nobody ever enters a collective alone).  On a GPU the 16-byte all-reduce and its
+    # copy to pinned host memory are stream-ordered and the result is read one call site later (finish_gradients - i.e.
+    # before the optimizer can apply the biased step - the next forward, check_exchange), so the check never drains the
+    # queue; on the host (gloo, tests) it is read at once.
+    @staticmethod
+    def _shape_signature(a, k):
         def shapes(o):
             if torch.is_tensor(o):
                 return tuple(o.shape)
@@ -303,17 +346,66 @@ class DataParallelOverRCCL(torch.nn.Module):
                 return tuple(shapes(v) for v in o)
             return None
 
-        sig = (shapes(a), shapes(k))
-        if sig == self._batch_sig:
+        return (shapes(a), shapes(k))
+
+    def _check_equal_batches(self, a, k):
+        if not (self.training and self.reducer.active and self._sync_bn and dist.is_initialized() and dist.get_world_size() > 1):
             return
-        every = [None] * dist.get_world_size()
-        dist.all_gather_object(every, sig)
-        if any(e != every[0] for e in every):
+        self._verify_batch_check()  # the previous call's result, if nobody has read it yet
+        import hashlib
+
+        sig = self._shape_signature(a, k)
+        src = self._sig_cache.get(sig)
+        dev = next(self.module.parameters()).device
+        if src is None:
+            h = int.from_bytes(hashlib.blake2b(repr(sig).encode(), digest_size=8).digest(), "little") >> 2
+            src = self._sig_cache[sig] = torch.tensor([h, -h], dtype=torch.int64).to(dev)
+        if dev.type != "cuda" or shared_gpu_test():
+            t = src.clone()
+            all_reduce(t, op=dist.ReduceOp.MAX)
+            self._sig_pending = (None, t.cpu(), sig)
+            self._verify_batch_check()
+            return
+        if self._sig_work is None:
+            self._sig_work = torch.empty(2, dtype=torch.int64, device=dev)
+            self._sig_host = torch.empty(2, dtype=torch.int64).pin_memory()
+            self._sig_stream = torch.cuda.Stream(device=dev)
+        self._sig_work.copy_(src)
+        all_reduce(self._sig_work, op=dist.ReduceOp.MAX)
+        if torch.cuda.is_current_stream_capturing():
+            return  # a captured step: the shapes are frozen with the graph (the capture's warm-up runs were checked)
+        cur = torch.cuda.current_stream()
+        self._sig_stream.wait_stream(cur)
+        with torch.cuda.stream(self._sig_stream):
+            self._sig_host.copy_(self._sig_work, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self._sig_stream)
+        cur.wait_stream(self._sig_stream)  # the work buffer is rewritten by the next call
+        self._sig_pending = (ev, self._sig_host, sig)
+
+    def _verify_batch_check(self):
+        pend, self._sig_pending = self._sig_pending, None
+        if pend is None:
+            return
+        ev, host, sig = pend
+        if ev is not None:
+            if torch.cuda.is_current_stream_capturing():  # no host waits inside a capture: keep it for the next call site
+                self._sig_pending = pend
+                return
+            ev.synchronize()
+        hi, neg_lo = (int(v) for v in host.tolist())
+        if hi != -neg_lo:
+            # every rank sees the same reduced pair, so every rank is here: a collective for the message is safe
+            every = [None] * dist.get_world_size()
+            try:
+                dist.all_gather_object(every, sig)
+            except Exception:  # noqa: BLE001 - the message is a courtesy, the error is not
+                every = ["rank %d: %r" % (dist.get_rank(), sig)]
             raise ValueError("SyncBN over %d ranks needs the same batch shape on every rank (drop_last); got %r"
-                             % (len(every), every))
-        self._batch_sig = sig
+                             % (dist.get_world_size(), every))
 
     def finish_gradients(self):
+        self._verify_batch_check()  # before the optimizer can apply a step taken on biased SyncBN statistics
         self.reducer.wait()
 
     def close(self):
@@ -326,5 +418,6 @@ class DataParallelOverRCCL(torch.nn.Module):
 
     def check_exchange(self):
         """Raise if a peer statistics exchange timed out (device sync: call where the loss is read anyway)."""
+        self._verify_batch_check()
         if self.exchange is not None:
             self.exchange.check()

@@ -108,6 +108,7 @@ class _BasicUpdateBlock(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------ launch helpers
+_THIN_OK = {}
 GEMM_FLOPS = {"total": 0.0}  # algorithmic FLOPs of the MFMA launches issued so far (tools/raft_bench.py reads / resets it)
 
 
@@ -120,7 +121,11 @@ def _conv(x, n, h, w, c, ldx, wt, bias, kh, kw, stride, pad, act, y, ldy):
     ow = (w + 2 * pw - (kw - 1) - 1) // stride + 1
     d = ConvDesc(n, h, w, c, oh, ow, k, kh, kw, stride, ph, 1, pw)
     GEMM_FLOPS["total"] += 2.0 * n * oh * ow * k * kh * kw * c
-    if _RAFT_THIN and int(_C.query("vspw_conv2d_thin_supported", ctypes.byref(d), ldx, ldy)):
+    thin_key = (n, h, w, c, k, kh, kw, stride, ph, pw, ldx, ldy)
+    thin = _THIN_OK.get(thin_key)
+    if thin is None:  # one query per geometry, not one per launch (20 iterations x every convolution of the update block)
+        thin = _THIN_OK[thin_key] = bool(_RAFT_THIN and int(_C.query("vspw_conv2d_thin_supported", ctypes.byref(d), ldx, ldy)))
+    if thin and ((x.value or 0) | wt.data_ptr()) % 16 == 0:  # (the kernel loads float4s: 16-byte aligned slots only)
         # 256 -> 2 channels: a direct kernel instead of an MFMA tile that is 97 % padding
         _C.call("vspw_conv2d_thin", ctypes.byref(d), x, ldx, _p(wt), _p(bias), act, y, ldy, _stream())
         return oh, ow

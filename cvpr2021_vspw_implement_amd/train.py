@@ -59,7 +59,14 @@ def train(segmentation_module, data_loader, optimizers, history, epoch, cfg, arg
             except Exception as e:  # state was restored by GraphedTrainStep: carry on launch by launch
                 log("hipGraph capture of the training step failed (%s: %s); running eagerly" % (type(e).__name__, e))
                 args.hip_graph = False
-        if graphed is not None and graphed.matches(imgs, gts):
+        use_graph = graphed is not None and graphed.matches(imgs, gts)
+        if not hasattr(args, "_hip_graph_requested"):  # (the flag itself is cleared on a rank whose capture failed)
+            args._hip_graph_requested = bool(getattr(args, "hip_graph", False))
+        if args._hip_graph_requested and vdist._world() > 1:
+            # a rank that replays its graph while a peer runs this step launch by launch (a batch of another shape
+            # there) would issue a different sequence of collectives: replay only when EVERY rank replays
+            use_graph = vdist.all_agree(use_graph)
+        if use_graph:
             loss, acc = graphed(imgs, gts)
         else:
             segmentation_module.zero_grad()
@@ -72,16 +79,17 @@ def train(segmentation_module, data_loader, optimizers, history, epoch, cfg, arg
                 optimizer.step()
         batch_time.update(time.time() - tic)
         tic = time.time()
-        vdist.step_guard(segmentation_module, loss.data.item())
-        ave_total_loss.update(loss.data.item())
-        ave_acc.update(acc.data.item() * 100)
+        loss_value, acc_value = loss.data.item(), acc.data.item()  # ONE device sync per step, paid here
+        vdist.step_guard(segmentation_module, loss_value)  # collective with more than one rank: all raise or none
+        ave_total_loss.update(loss_value)
+        ave_acc.update(acc_value * 100)
         log("Epoch: [{}][{}/{}], Time: {:.2f}, Data: {:.2f}, lr_encoder: {:.6f}, lr_decoder: {:.6f}, "
             "Accuracy: {:4.2f}, Loss: {:.6f}".format(epoch, i, epoch_iters, batch_time.average(), data_time.average(),
                                                      cfg.TRAIN.running_lr_encoder, cfg.TRAIN.running_lr_decoder,
                                                      ave_acc.average(), ave_total_loss.average()))
         history["train"]["epoch"].append(epoch - 1 + 1. * i / epoch_iters)
-        history["train"]["loss"].append(loss.data.item())
-        history["train"]["acc"].append(acc.data.item())
+        history["train"]["loss"].append(loss_value)
+        history["train"]["acc"].append(acc_value)
 
 
 def test(segmentation_module, loader, args, transform, log=print, world=1):

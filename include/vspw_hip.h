@@ -140,9 +140,12 @@ int vspw_weight_transpose_multi(const vspw_wt_entry* entries, int n_entries, lon
  * 252-274) runs on.  k: multiple of 32; 0 = one chain = the default (chains of 256 halve the error of a K >= 1024 GEMM
  * but cost 3 % of the training step and move the end-to-end parity figures by < 0.1x: the excess over the reference's
  * own fp32 noise sat in the direct 3x3 kernels, which fold their chains every 96 terms unconditionally - DESIGN.md
- * section 4).  Process-wide policy, not per-call state: set it before issuing work. */
+ * section 4).  Process-wide policy, not per-call state: set it before issuing work.
+ * The chunked variants are compiled only into diagnostic builds (-DVSPW_WITH_ACCUM_CHUNK, tools/diag/build_variant.py;
+ * vspw_accum_chunk_compiled() == 1): the shipped library accepts k = 0 only and returns VSPW_EINVAL otherwise. */
 int vspw_set_accum_chunk(int k);
 int vspw_get_accum_chunk(void);
+int vspw_accum_chunk_compiled(void);
 /* Diagnostics: shader cycles (out[0]) and 100 MHz wall-clock ticks (out[1]) that workgroup 0 of every forward / data-
  * gradient GEMM launch spent between its first and last instruction since the last reset - their ratio x 0.1 is the shader
  * clock in GHz the chip sustained under that load (measured 1.87 ... 2.40 GHz on the same GEMM depending on operand values
@@ -150,6 +153,9 @@ int vspw_get_accum_chunk(void);
  * roofline.sustained_clock_ghz).
  * Synchronises the device.  reset != 0: zero the sums afterwards. */
 int vspw_debug_nt_clock(unsigned long long* out, int reset);
+/* The probe is OFF by default (an unarmed launch pays one scalar load): on != 0 arms it, 0 disarms it.  Synchronises the
+ * device.  Arm it only around launches issued one after the other on one stream (one start stamp per device). */
+int vspw_debug_nt_clock_enable(int on);
 /* [n][c][hw] -> [n][hw][c]: the reference feeds NCHW images (train_clip2.py:45-47). */
 int vspw_nchw_to_nhwc(const float* in, float* out, int n, int c, long long hw, void* stream);
 

@@ -166,13 +166,29 @@ def _guard_worker(rank, world, port, q):
     wrapped(full[rank * 2:(rank + 1) * 2]).backward()
     wrapped.finish_gradients()
     wrapped(full[rank * 2:(rank + 1) * 2])
-    # the drivers' per-step guard: a finite loss passes, a non-finite one raises before it can reach a checkpoint
+    # ONE rank's batch changes mid-run (a short last batch on rank 1 at step 3, its peers' signature unchanged): the
+    # comparison is unconditional and symmetric, so EVERY rank raises - nobody is left alone in a collective
+    mid = []
+    for step in range(5):
+        rows = 1 if (step == 3 and rank == 1) else 2
+        try:
+            wrapped(full[rank * 2:rank * 2 + rows]).backward()
+            wrapped.finish_gradients()
+            mid.append(False)
+        except ValueError as e:
+            mid.append("same batch shape on every rank" in str(e))
+    raised = raised and mid == [False, False, False, True, False]
+    # the drivers' per-step guard: a finite loss passes everywhere; a non-finite one on ONE rank stops EVERY rank in
+    # the same step - FloatingPointError where it happened, PeerAbort on the others
     vdist.step_guard(wrapped, 1.25)
     try:
-        vdist.step_guard(wrapped, float("nan"))
+        vdist.step_guard(wrapped, float("nan") if rank == 0 else 0.5)
         nan_raised = False
     except FloatingPointError:
-        nan_raised = True
+        nan_raised = rank == 0
+    except vdist.PeerAbort:
+        nan_raised = rank != 0
+    assert vdist.all_agree(True) and not vdist.all_agree(rank == 0)
     vdist.checkpoint_barrier()  # every rank: returns
     wrapped.close()
     from cvpr2021_vspw_implement_amd import ops

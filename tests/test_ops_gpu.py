@@ -186,6 +186,8 @@ def test_pointwise_two_level_accumulation(dev, n, c, h, w, k, bias):
     reference's k-blocked CPU GEMM has the smaller error - profiles/r05_parity_attrib.log)."""
     from cvpr2021_vspw_implement_amd import ops
 
+    if not ops.accum_chunk_supported():
+        pytest.skip("diagnostic builds only (-DVSPW_WITH_ACCUM_CHUNK, tools/diag/build_variant.py)")
     g = torch.Generator().manual_seed(5 + c + k)
     x = torch.randn(n, c, h, w, generator=g)
     wt = torch.randn(k, c, 1, 1, generator=g) * (2.0 / c) ** 0.5
@@ -230,6 +232,8 @@ def accum_chunk(request):
     epilogues / staged operands must compose with the parked partial sums."""
     from cvpr2021_vspw_implement_amd import ops
 
+    if request.param and not ops.accum_chunk_supported():
+        pytest.skip("diagnostic builds only (-DVSPW_WITH_ACCUM_CHUNK, tools/diag/build_variant.py)")
     prev = ops.set_accum_chunk(request.param)
     yield request.param
     ops.set_accum_chunk(prev)

@@ -146,8 +146,8 @@ def test_480p_inference_against_reference_vectors(dev, kind, cfg, variant):
     assert np.abs(probs.sum(1) - 1).max() < 1e-5
     assert (flips & decisive).sum() == 0
     own_flips = int((fx["argmax32"] != fx["argmax64"]).sum())
-    if variant == "damped":  # no more disagreement with the reference's fp32 masks than 4x its own fp32-vs-fp64 count
-        assert flips.sum() <= 4 * max(own_flips, 25), flips.sum()
+    if variant == "damped":  # no more disagreement with the reference's fp32 masks than 3x its own fp32-vs-fp64 count (measured worst: 2.6x)
+        assert flips.sum() <= 3 * max(own_flips, 25), flips.sum()
     else:  # (two fp32 realisations differ ~1.4x more often from each other than either does from float64)
         assert flips.sum() <= RAW_FLIPS * max(own_flips, 25), (flips.sum(), own_flips)
 

@@ -877,6 +877,8 @@ def plane_shift(x, out_hw, top, left):
     """out[..., y, x] = x[..., y - top, x - left], zero outside (no autograd: image / frozen-flow plumbing): constant
     padding for top, left >= 0, a crop for negative offsets."""
     _require_gpu(x, "plane_shift")
+    if x.dtype != torch.float32:
+        raise TypeError("plane_shift: float32 planes only (got %s); callers cast like the reference's .float() call sites" % x.dtype)
     x = x.contiguous()
     n, c, h, w = x.shape
     y = torch.empty((n, c, int(out_hw[0]), int(out_hw[1])), device=x.device, dtype=torch.float32)

@@ -111,7 +111,9 @@ class PeerExchange:
         try:
             w = self.world
             # test hook (tests/test_bench_gpu.py): this rank reports a failed self-test - EVERY rank must then fall back
-            if os.environ.get("VSPW_PEER_SELFTEST_FAIL_RANK") == str(self.rank):
+            # failure injection for tests/test_bench_gpu.py: honoured in the shared-GPU TEST MODE only
+            if (os.environ.get("VSPW_PEER_SELFTEST_FAIL_RANK") == str(self.rank)
+                    and (os.environ.get("VSPW_SHARED_GPU_TEST") == "1" or os.environ.get("VSPW_BENCH_SHARED_GPU") == "1")):
                 self.why = "self-test: failure injected on rank %d (VSPW_PEER_SELFTEST_FAIL_RANK)" % self.rank
             for k in range(48):
                 n = [1, 2, 130, 1024, 4096, self.SLOT_DOUBLES][k % 6]

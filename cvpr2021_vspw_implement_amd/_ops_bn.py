@@ -258,11 +258,13 @@ def _conv_bn_folded(x, w, cbias, gamma, beta, running_mean, running_var, residua
         residual = to_nhwc(residual)
         if tuple(residual.shape) != tuple(z.shape):
             raise RuntimeError("conv_bn_act: residual %s vs output %s" % (tuple(residual.shape), tuple(z.shape)))
-    if _wino_ok(d) and _wino_f3(d):  # stride-1 3x3: Winograd F(3x3,3x3) on the folded weights (transform cached with them)
-        if ent[3] is None or ent[3].shape[0] != 25:
-            ent[3] = torch.empty((25, k, c), device=x.device, dtype=torch.float32)
-            _C.call("vspw_wino3_weights", _p(wf), _p(ent[3]), k, c, 0, st)
-        _wino3_conv(d, x, None, k, c, False, bf, z, what="fwd-fold", u=ent[3], addend=residual, act=1 if relu else 0)
+    fm = _wino_f3(d) if _wino_ok(d) else 0
+    if fm:  # stride-1 3x3: Winograd F(3x3,3x3) / F(4x4,3x3) on the folded weights (transform cached with them)
+        planes = (fm + 2) * (fm + 2)
+        if ent[3] is None or ent[3].shape[0] != planes:
+            ent[3] = torch.empty((planes, k, c), device=x.device, dtype=torch.float32)
+            _C.call("vspw_wino%d_weights" % fm, _p(wf), _p(ent[3]), k, c, 0, st)
+        _wino3_conv(d, x, None, k, c, False, bf, z, what="fwd-fold", u=ent[3], addend=residual, act=1 if relu else 0, m=fm)
         return z
     if _wino_ok(d):  # ... F(2x2,3x3) (VSPW_WINO_F3=0)
         if ent[3] is None or ent[3].shape[0] != 16:

@@ -33,11 +33,14 @@ _wino = {"enabled": os.environ.get("VSPW_WINOGRAD", "1") == "1", "min_c": int(os
          "fuse_max_rows": int(os.environ.get("VSPW_WINO_FUSE_MAXROWS", "512")),
          # the four GEMMs of a transform row in one workgroup (csrc/wino_rows.hip) where the library expects it to win
          "rows": os.environ.get("VSPW_WINO_ROWS", "1") == "1",
-         # F(3x3,3x3) (csrc/winograd_f3.hip): 25 GEMMs over 3x3 output tiles - 25/81 of the direct multiplications
-         # instead of 36/81, no padded tiles on the 60 / 30 / 15 pixel sub-grids.  VSPW_WINO_F3=0: F(2x2) everywhere;
-         # VSPW_WINO_F3_MINC: smallest channel count (both sides) that takes it
-         "f3": os.environ.get("VSPW_WINO_F3", "1") == "1", "f3_min_c": int(os.environ.get("VSPW_WINO_F3_MINC", "128")),
-         "f3_launches": 0}
+         # F(3x3,3x3) / F(4x4,3x3) (csrc/winograd_f3.hip): 25 / 36 GEMMs over 3x3 / 4x4 output tiles - 25/81 resp. 36/144 of the
+         # direct multiplications instead of F(2x2)'s 36/81.  "tile": 0 = per geometry the size that executes fewer
+         # multiplications (3 divides the 30 / 15 pixel sub-grids of the dilated stages, 4 divides 60), 2 / 3 / 4 = forced
+         # (VSPW_WINO_TILE; VSPW_WINO_F3=0 is the old spelling of 2).  VSPW_WINO_F3_MINC: smallest channel count (both
+         # sides) that leaves F(2x2)
+         "tile": 2 if os.environ.get("VSPW_WINO_F3", "1") != "1" else int(os.environ.get("VSPW_WINO_TILE", "0")),
+         "f3_min_c": int(os.environ.get("VSPW_WINO_F3_MINC", "128")), "f3_launches": 0, "f4_launches": 0}
+_wino_tile_cache = {}
 
 
 _strided_pw = {"enabled": os.environ.get("VSPW_STRIDED_PW_DGRAD", "1") == "1"}  # compact GEMM + scatter (conv2d_backward_data)
@@ -66,36 +69,71 @@ def _wino_ok(d):
 
 
 def set_winograd_f3(enabled):
-    prev = _wino["f3"]
-    _wino["f3"] = bool(enabled)
-    return prev
+    """False: F(2x2,3x3) everywhere (round-5 behaviour); True: automatic tile size.  Returns the previous setting as a
+    value this function accepts back (True / False / a forced tile)."""
+    return set_winograd_tile(0 if enabled is True else (2 if enabled is False else int(enabled)))
+
+
+def set_winograd_tile(m):
+    """0: automatic, 2 / 3 / 4: force F(m x m, 3x3) where the geometry allows it.  Returns the previous value."""
+    if m not in (0, 2, 3, 4):
+        raise ValueError("Winograd tile %r" % (m,))
+    prev = _wino["tile"]
+    _wino["tile"] = m
+    return False if prev == 2 else (True if prev == 0 else prev)
 
 
 def _wino_f3(d):
-    """True when this (Winograd-eligible, see _wino_ok) convolution takes F(3x3,3x3) in all three passes."""
-    return (_wino["f3"] and min(d.c, d.k) >= _wino["f3_min_c"]
-            and _C.query("vspw_wino3_supported", ctypes.byref(d)) == 1)
+    """Output tile edge m (3 or 4) when this (Winograd-eligible, see _wino_ok) convolution leaves F(2x2) in all three
+    passes - forward, data gradient and weight gradient decide alike, they share V - else 0."""
+    t = _wino["tile"]
+    if t == 2 or min(d.c, d.k) < _wino["f3_min_c"]:
+        return 0
+    key = (t, d.n, d.h, d.w, d.c, d.k, d.dil, d.pad, d.pad_w, d.stride, d.kh, d.kw)
+    m = _wino_tile_cache.get(key)
+    if m is None:
+        ok3 = _C.query("vspw_wino3_supported", ctypes.byref(d)) == 1
+        ok4 = _C.query("vspw_wino4_supported", ctypes.byref(d)) == 1
+        if t == 3:
+            m = 3 if ok3 else 0
+        elif t == 4:
+            m = 4 if ok4 else (3 if ok3 else 0)
+        elif ok3 and ok4:
+            # executed multiplications per (cin, cout) pair = tiles x positions.  Measured (tools/diag/wino3_probe.py,
+            # profiles/r06_wino34_probe.log, us for the three passes, F(3x3) -> F(4x4)): F(4x4) wins where the GEMMs dominate
+            # its 36-plane transforms, i.e. from 512 channels on - the heads' 1024 / 4096 -> 512 on undilated 60x60 maps
+            # (19 % fewer multiplications) 2837 -> 2446 and 2388 -> 2019, the dilated 512 -> 512 of layer 4 (30 -> 32 / 15 -> 16
+            # padding: 8 % fewer) 1530 -> 1472; it loses on 256 channels with dilation (503 -> 537) and on 128 (194 -> 207)
+            t3, t4 = int(_C.query("vspw_wino3_tiles", ctypes.byref(d))), int(_C.query("vspw_wino4_tiles", ctypes.byref(d)))
+            m = 4 if (36 * t4 <= 0.95 * 25 * t3 and min(d.c, d.k) >= 512) else 3
+        else:
+            m = 3 if ok3 else (4 if ok4 else 0)
+        _wino_tile_cache[key] = m
+    return m
 
 
 def _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, part=None, what="fwd", u=None,
-                addend=None, act=0):
-    """_wino_conv through F(3x3,3x3): input transform, 25 batched GEMMs, output transform (winograd_f3.hip)."""
+                addend=None, act=0, m=None):
+    """_wino_conv through F(m x m, 3x3), m = 3 or 4: input transform, (m+2)^2 batched GEMMs, output transform
+    (winograd_f3.hip)."""
     dev, st = src.device, _stream()
-    T = int(_C.query("vspw_wino3_tiles", ctypes.byref(d)))
+    m = m or _wino_f3(d)
+    P, api = (m + 2) * (m + 2), "vspw_wino%d_" % m
+    T = int(_C.query(api + "tiles", ctypes.byref(d)))
     if u is None:
-        u = _wino3_weights(w, data_gradient)
-    v = torch.empty((25, T, reduce_c), device=dev, dtype=torch.float32)
-    _C.call("vspw_wino3_input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
-    m = torch.empty((25, T, rows), device=dev, dtype=torch.float32)
-    with _Timed("igemm_nt_kernel", 2.0 * 25 * T * rows * reduce_c, _conv_tag(d, what + "-wino3"), _conv_flops(d)):
-        _C.call("vspw_bmm_nt", _p(v), _p(u), _p(m), 25, T, rows, reduce_c, st)
+        u = _wino3_weights(w, data_gradient, m)
+    v = torch.empty((P, T, reduce_c), device=dev, dtype=torch.float32)
+    _C.call(api + "input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
+    mm = torch.empty((P, T, rows), device=dev, dtype=torch.float32)
+    with _Timed("igemm_nt_kernel", 2.0 * P * T * rows * reduce_c, _conv_tag(d, what + "-wino%d" % m), _conv_flops(d)):
+        _C.call("vspw_bmm_nt", _p(v), _p(u), _p(mm), P, T, rows, reduce_c, st)
     z = y_ = mean = invstd = None
     if front is not None:
         z, y_, mean, invstd = front
-    _C.call("vspw_wino3_output", ctypes.byref(d), _p(m), rows, _p(bias), _p(dst), _p(z), _p(y_), _p(mean), _p(invstd),
+    _C.call(api + "output", ctypes.byref(d), _p(mm), rows, _p(bias), _p(dst), _p(z), _p(y_), _p(mean), _p(invstd),
             _p(part), _p(addend), act, st)
     _wino["launches"] += 1
-    _wino["f3_launches"] += 1
+    _wino["f%d_launches" % m] += 1
     return v
 
 
@@ -181,8 +219,8 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None,
     part = None
     if _wino_ok(d) and (pending is None or _wino_takes_pending(d, pending, wgrad)):
         if want_stats:
-            nparts = _C.query("vspw_wino3_stat_partials" if (pending is None and _wino_f3(d)) else "vspw_wino_stat_partials",
-                              ctypes.byref(d))
+            fm = _wino_f3(d) if pending is None else 0
+            nparts = _C.query(("vspw_wino%d_stat_partials" % fm) if fm else "vspw_wino_stat_partials", ctypes.byref(d))
             part = torch.empty((nparts, 2, k), device=x.device, dtype=torch.float32)
         # the input transform is kept for this convolution's weight gradient (same V: saves its recomputation there) -
         # only when there will be one: frozen weights / no_grad evaluation take the GEMM that transforms its A operand
@@ -331,24 +369,28 @@ _wu_copies = _DerivedWeights(_wu_alloc, _wu_single, "vspw_wino_weights_multi",
                              lambda k, c, kh, kw: _C.query("vspw_wino_weight_tiles", k, c))
 
 
-def _wu3_alloc(w):
-    k, c, kh, kw = w.shape
-    return torch.empty((2, 25, k * c), device=w.device, dtype=torch.float32)
+def _wum_cache(m):
+    P = (m + 2) * (m + 2)
+
+    def alloc(w):
+        k, c, kh, kw = w.shape
+        return torch.empty((2, P, k * c), device=w.device, dtype=torch.float32)
+
+    def single(w, buf, st):
+        k, c, kh, kw = w.shape
+        _C.call("vspw_wino%d_weights" % m, _p(w), _p(buf[0]), k, c, 0, st)
+        _C.call("vspw_wino%d_weights" % m, _p(w), _p(buf[1]), k, c, 1, st)
+
+    return _DerivedWeights(alloc, single, "vspw_wino%d_weights_multi" % m,
+                           lambda k, c, kh, kw: _C.query("vspw_wino_weight_tiles", k, c))
 
 
-def _wu3_single(w, buf, st):
-    k, c, kh, kw = w.shape
-    _C.call("vspw_wino3_weights", _p(w), _p(buf[0]), k, c, 0, st)
-    _C.call("vspw_wino3_weights", _p(w), _p(buf[1]), k, c, 1, st)
+_wu3_copies = {3: _wum_cache(3), 4: _wum_cache(4)}
 
 
-_wu3_copies = _DerivedWeights(_wu3_alloc, _wu3_single, "vspw_wino3_weights_multi",
-                              lambda k, c, kh, kw: _C.query("vspw_wino_weight_tiles", k, c))
-
-
-def _wino3_weights(w, data_gradient):
-    """U [25][Cout][Cin] (forward) or U' [25][Cin][Cout] (data gradient) of a 3x3 weight, from the per-step cache."""
-    return _wu3_copies.get(w)[1 if data_gradient else 0]
+def _wino3_weights(w, data_gradient, m=3):
+    """U [(m+2)^2][Cout][Cin] (forward) or U' [..][Cin][Cout] (data gradient) of a 3x3 weight, from the per-step cache."""
+    return _wu3_copies[m].get(w)[1 if data_gradient else 0]
 
 
 def _wino_weights(w, data_gradient):
@@ -359,7 +401,8 @@ def _wino_weights(w, data_gradient):
 def drop_weight_transpose_cache():
     _wt_copies.clear()
     _wu_copies.clear()
-    _wu3_copies.clear()
+    for cache in _wu3_copies.values():
+        cache.clear()
 
 
 def conv2d_backward_data(dy, w, d, addend=None, bn_front=None, aff=None):
@@ -375,7 +418,8 @@ def conv2d_backward_data(dy, w, d, addend=None, bn_front=None, aff=None):
         if bn_front is not None:
             z, link = bn_front
             front = (z, link.y, link.mean, link.invstd)
-            part = torch.empty((_C.query("vspw_wino3_stat_partials" if _wino_f3(d) else "vspw_wino_stat_partials",
+            fm = _wino_f3(d)
+            part = torch.empty((_C.query(("vspw_wino%d_stat_partials" % fm) if fm else "vspw_wino_stat_partials",
                                          ctypes.byref(d)), 2, d.c), device=dy.device, dtype=torch.float32)
         _wino_conv(d, dy, w, d.c, d.k, True, None, dx, front=front, part=part, what="dgrad")
         if bn_front is not None:
@@ -457,21 +501,23 @@ def _wino_wgrad(dy, x, d, dw, v=None):
     """dW of a stride-1 3x3 convolution in the Winograd domain (see winograd.hip): 4/9 of the direct multiplications.
     v: the input transform kept by the forward pass (recomputed from x when absent)."""
     dev, st = dy.device, _stream()
-    if _wino_f3(d):
-        T = int(_C.query("vspw_wino3_tiles", ctypes.byref(d)))
-        if v is None or tuple(v.shape) != (25, T, d.c):
-            v = torch.empty((25, T, d.c), device=dev, dtype=torch.float32)
-            _C.call("vspw_wino3_input", ctypes.byref(d), _p(x), d.c, _p(v), st)
-        dm = torch.empty((25, T, d.k), device=dev, dtype=torch.float32)
-        _C.call("vspw_wino3_dy", ctypes.byref(d), _p(dy), d.k, _p(dm), st)
-        du = torch.empty((25, d.k, d.c), device=dev, dtype=torch.float32)
-        nbytes = _C.query("vspw_bmm_tn_workspace", 25, T, d.k, d.c)
+    fm = _wino_f3(d)
+    if fm:
+        P, api = (fm + 2) * (fm + 2), "vspw_wino%d_" % fm
+        T = int(_C.query(api + "tiles", ctypes.byref(d)))
+        if v is None or tuple(v.shape) != (P, T, d.c):
+            v = torch.empty((P, T, d.c), device=dev, dtype=torch.float32)
+            _C.call(api + "input", ctypes.byref(d), _p(x), d.c, _p(v), st)
+        dm = torch.empty((P, T, d.k), device=dev, dtype=torch.float32)
+        _C.call(api + "dy", ctypes.byref(d), _p(dy), d.k, _p(dm), st)
+        du = torch.empty((P, d.k, d.c), device=dev, dtype=torch.float32)
+        nbytes = _C.query("vspw_bmm_tn_workspace", P, T, d.k, d.c)
         ws = _ws(nbytes, dev) if nbytes else None
-        with _Timed("igemm_tn_kernel", 2.0 * 25 * T * d.k * d.c, _conv_tag(d, "wgrad-wino3"), _conv_flops(d)):
-            _C.call("vspw_bmm_tn", _p(dm), _p(v), _p(du), 25, T, d.k, d.c, _p(ws), nbytes, st)
-        _C.call("vspw_wino3_dw", _p(du), _p(dw), d.k, d.c, st)
+        with _Timed("igemm_tn_kernel", 2.0 * P * T * d.k * d.c, _conv_tag(d, "wgrad-wino%d" % fm), _conv_flops(d)):
+            _C.call("vspw_bmm_tn", _p(dm), _p(v), _p(du), P, T, d.k, d.c, _p(ws), nbytes, st)
+        _C.call(api + "dw", _p(du), _p(dw), d.k, d.c, st)
         _wino["launches"] += 1
-        _wino["f3_launches"] += 1
+        _wino["f%d_launches" % fm] += 1
         return
     T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
     if v is None or tuple(v.shape) != (16, T, d.c):

@@ -1,4 +1,5 @@
-// Winograd F(3x3, 3x3) for the stride-1 3x3 convolutions of the path (forward, data gradient, weight gradient).
+// Winograd F(3x3, 3x3) and F(4x4, 3x3) for the stride-1 3x3 convolutions of the path (forward, data gradient, weight
+// gradient).  One template over the output tile edge M; the text below describes M = 3, the F(4x4) notes follow it.
 //
 // Round 6.  F(2x2, 3x3) (winograd.hip) executes 16 multiplications per 4 outputs (4.0 per output pixel, 4/9 of the direct
 // count) and pads the 15 x 15 dilation sub-grids of the dilation-4 stage to 16 x 16 (13.8 % surplus).  F(3x3, 3x3) computes
@@ -17,33 +18,36 @@
 // Dilation d: d*d independent undilated convolutions on the sub-grids {(y, x): y = sy (mod d), x = sx (mod d)}, tiles laid
 // out per (image, sub-grid) as in winograd.hip.  Ragged edges are zero-padded tiles whose surplus outputs are dropped.
 // Layouts: activations NHWC; V [25][T][Cin], U [25][Cout][Cin], M [25][T][Cout], T = n * d*d * th * tw tiles.
+// F(4x4, 3x3) (M = 4): a 4x4 output tile from a 6x6 patch over the points {0, 1, -1, 1/2, -2, inf} - 36 multiplications
+// per 16 outputs = 2.25 per output pixel.  4 divides 60 exactly (the undilated shapes: heads, layer3.0, layer2); the 30 / 15
+// pixel sub-grids of dilation 2 / 4 pad to 32 / 16 (13.8 % surplus: 2.56 per output, still 8 % below F(3x3)).  The point set
+// was chosen by the conv-level probe (tools/diag/wino_f33_probe.py): {0, +-1, 1/2, -2} gives 1.65e-6 forward error on a
+// layer-3 convolution - F(3x3): 1.45e-6 - where the textbook {0, +-1, +-2} gives 2.5e-6; B^T and A^T entries stay exact
+// binary fractions (1/2, 3/2, 5/2, 1/4, 1/8, 8), G has 1/3, 1/15, 16/15 (fp64, rounded once).  ops._wino_fm picks, per
+// geometry, the tile size that executes fewer multiplications.
 // Reference call sites: the 3x3 convolutions of models/resnet.py:72-92 after models/models.py:737-750, the heads'
 // models/clip_psp.py:29-35,74-79, models/clip_ocr.py:41-52 (F.conv2d, and its two gradients under loss.backward(),
 // train_clip2.py:99).
 #include "common.h"
 
-constexpr int WM = 3;       // output tile edge
-constexpr int WN = WM + 2;  // input patch edge
-constexpr int WP = WN * WN; // transform positions
-
-// B^T [5][5], A^T [3][5] (fp32: small integers), G [5][3] (fp64)
-__device__ constexpr float kBT[WN][WN] = {{2.f, -1.f, -2.f, 1.f, 0.f},
-                                          {0.f, -2.f, -1.f, 1.f, 0.f},
-                                          {0.f, 2.f, -3.f, 1.f, 0.f},
-                                          {0.f, -1.f, 0.f, 1.f, 0.f},
-                                          {0.f, 2.f, -1.f, -2.f, 1.f}};
-__device__ constexpr float kAT[WM][WN] = {{1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, 0.f}, {0.f, 1.f, 1.f, 4.f, 1.f}};
-__device__ constexpr double kG[WN][3] = {{0.5, 0., 0.},
-                                         {-0.5, -0.5, -0.5},
-                                         {-1. / 6., 1. / 6., -1. / 6.},
-                                         {1. / 6., 1. / 3., 2. / 3.},
-                                         {0., 0., 1.}};
+// B^T [N][N], A^T [M][N] (fp32: exact binary fractions), G [N][3] (fp64); N = M + 2.  Generated from the Cook-Toom
+// construction of oracle/np_wino.py (points {0,1,-1,2,inf} and {0,1,-1,1/2,-2,inf}).
+__device__ constexpr float kBT3[5][5] = {{2.f, -1.f, -2.f, 1.f, 0.f}, {0.f, -2.f, -1.f, 1.f, 0.f}, {0.f, 2.f, -3.f, 1.f, 0.f}, {0.f, -1.f, 0.f, 1.f, 0.f}, {0.f, 2.f, -1.f, -2.f, 1.f}};
+__device__ constexpr float kAT3[3][5] = {{1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, 0.f}, {0.f, 1.f, 1.f, 4.f, 1.f}};
+__device__ constexpr double kG3[5][3] = {{1. / 2., 0., 0.}, {-1. / 2., -1. / 2., -1. / 2.}, {-1. / 6., 1. / 6., -1. / 6.}, {1. / 6., 1. / 3., 2. / 3.}, {0., 0., 1.}};
+__device__ constexpr float kBT4[6][6] = {{1.f, -3.f / 2.f, -2.f, 3.f / 2.f, 1.f, 0.f}, {0.f, -1.f, 1.f / 2.f, 5.f / 2.f, 1.f, 0.f}, {0.f, 1.f, -5.f / 2.f, 1.f / 2.f, 1.f, 0.f}, {0.f, -2.f, -1.f, 2.f, 1.f, 0.f}, {0.f, 1.f / 2.f, -1.f, -1.f / 2.f, 1.f, 0.f}, {0.f, 1.f, -3.f / 2.f, -2.f, 3.f / 2.f, 1.f}};
+__device__ constexpr float kAT4[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 1.f / 2.f, -2.f, 0.f}, {0.f, 1.f, 1.f, 1.f / 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 1.f / 8.f, -8.f, 1.f}};
+__device__ constexpr double kG4[6][3] = {{1., 0., 0.}, {1. / 3., 1. / 3., 1. / 3.}, {-1. / 3., 1. / 3., -1. / 3.}, {-16. / 15., -8. / 15., -4. / 15.}, {1. / 15., -2. / 15., 4. / 15.}, {0., 0., 1.}};
+template <int M> __device__ __forceinline__ constexpr float cBT(int a, int i) { if constexpr (M == 3) return kBT3[a][i]; else return kBT4[a][i]; }
+template <int M> __device__ __forceinline__ constexpr float cAT(int a, int i) { if constexpr (M == 3) return kAT3[a][i]; else return kAT4[a][i]; }
+template <int M> __device__ __forceinline__ constexpr double cG(int a, int i) { if constexpr (M == 3) return kG3[a][i]; else return kG4[a][i]; }
 
 struct Geom {
     int n, h, w, d;      // images, height, width, dilation
     int th, tw, tpi, T;  // tiles per sub-grid column / row, tiles per image, total
 };
 
+template <int WM>
 static bool geom(const vspw_conv_desc* dsc, Geom& g) {
     if (!dsc || dsc->kh != 3 || dsc->kw != 3 || dsc->stride != 1 || dsc->dil < 1 || dsc->pad != dsc->dil ||
         dsc->pad_w != dsc->dil || dsc->oh != dsc->h || dsc->ow != dsc->w || dsc->n < 1)
@@ -75,7 +79,9 @@ __device__ __forceinline__ void tile_of(const Geom& g, int t, int& img, int& sy,
 // U = G g G^T.  w: [K][3][3][C] (channels_last OIHW).
 // mode bit 0 (forward):        U[xi][k][c] from g = w[k, :, :, c]
 // mode bit 1 (data gradient):  U[xi][c][k] from g = w[k, 2-ky, 2-kx, c]   (rows = Cin, reduction over Cout)
-__device__ __forceinline__ void weight_g(const float g[9], float u[WP]) {
+template <int WM>
+__device__ __forceinline__ void weight_g(const float g[9], float* u) {
+    constexpr int WN = WM + 2;
     double t[WN][3];
 #pragma unroll
     for (int a = 0; a < WN; ++a)
@@ -84,7 +90,7 @@ __device__ __forceinline__ void weight_g(const float g[9], float u[WP]) {
             double s = 0.;
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                if (kG[a][i] != 0.) s += kG[a][i] * (double)g[i * 3 + j];
+                if (cG<WM>(a, i) != 0.) s += cG<WM>(a, i) * (double)g[i * 3 + j];
             t[a][j] = s;
         }
 #pragma unroll
@@ -94,13 +100,16 @@ __device__ __forceinline__ void weight_g(const float g[9], float u[WP]) {
             double s = 0.;
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                if (kG[b][j] != 0.) s += t[a][j] * kG[b][j];
+                if (cG<WM>(b, j) != 0.) s += t[a][j] * cG<WM>(b, j);
             u[a * WN + b] = (float)s;
         }
 }
 
+template <int WM>
 __device__ __forceinline__ void weight_tile(const float* __restrict__ w, float* __restrict__ u, float* __restrict__ u2,
                                             int K, int C, int modes, int c0, int k0) {
+    constexpr int WN = WM + 2, WP = WN * WN;
+    (void)WN;
     __shared__ float gs[9][32][33];  // [tap][k][c]
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     for (int kk = ty; kk < 32; kk += 8) {
@@ -115,7 +124,7 @@ __device__ __forceinline__ void weight_tile(const float* __restrict__ w, float* 
         if (modes & 1) {  // row = k (rr), column = c (tx): coalesced along c
 #pragma unroll
             for (int t = 0; t < 9; ++t) g[t] = gs[t][rr][tx];
-            weight_g(g, uu);
+            weight_g<WM>(g, uu);
             const int k = k0 + rr, c = c0 + tx;
             if (k < K && c < C)
 #pragma unroll
@@ -124,7 +133,7 @@ __device__ __forceinline__ void weight_tile(const float* __restrict__ w, float* 
         if (modes & 2) {  // row = c (rr), column = k (tx): coalesced along k; filter rotated by 180 degrees
 #pragma unroll
             for (int t = 0; t < 9; ++t) g[t] = gs[8 - t][tx][rr];
-            weight_g(g, uu);
+            weight_g<WM>(g, uu);
             const int c = c0 + rr, k = k0 + tx;
             if (k < K && c < C)
 #pragma unroll
@@ -133,12 +142,14 @@ __device__ __forceinline__ void weight_tile(const float* __restrict__ w, float* 
     }
 }
 
+template <int WM>
 __global__ __launch_bounds__(256) void wino3_weight_kernel(const float* __restrict__ w, float* __restrict__ u, int K, int C,
                                                      int mode) {
-    weight_tile(w, u, u, K, C, mode == 0 ? 1 : 2, blockIdx.x * 32, blockIdx.y * 32);
+    weight_tile<WM>(w, u, u, K, C, mode == 0 ? 1 : 2, blockIdx.x * 32, blockIdx.y * 32);
 }
 
 // Both transforms of MANY weight tensors in one launch (cf. wino_weight_multi_kernel): entry.wT -> [2][25][K*C].
+template <int WM>
 __global__ __launch_bounds__(256) void wino3_weight_multi_kernel(const vspw_wt_entry* __restrict__ entries, int n_entries) {
     const long long b = blockIdx.x;
     int lo = 0, hi = n_entries - 1;
@@ -152,15 +163,19 @@ __global__ __launch_bounds__(256) void wino3_weight_multi_kernel(const vspw_wt_e
     const vspw_wt_entry e = entries[lo];
     const int local = (int)(b - e.tile0);
     const int tc = (e.c + 31) / 32;
-    weight_tile(e.w, e.wT, e.wT + (size_t)WP * e.k * e.c, e.k, e.c, 3, (local % tc) * 32, (local / tc) * 32);
+    weight_tile<WM>(e.w, e.wT, e.wT + (size_t)(WM + 2) * (WM + 2) * e.k * e.c, e.k, e.c, 3, (local % tc) * 32, (local / tc) * 32);
 }
 
 // ------------------------------------------------------------------------------------------------ input
 // V[xi][t][c] = (B^T d B)[xi].  One thread: one tile, 4 channels; patch rows are consumed as they arrive
 // (row i contributes BT[a][i] * (d[i][.] B)[b] to every V[a][b]).
+template <int WM>
 __global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restrict__ x, float* __restrict__ v, Geom g, int C) {
+    constexpr int WN = WM + 2;
     const int c4n = C >> 2;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    // XCD-aware order: neighbouring tiles share two of their five patch columns / rows - keep them in one L2 (measured
+    // before: FETCH_SIZE 83 MB per launch for a 37 MB input, workgroups of neighbouring tiles landing on eight XCDs)
+    const long long gid = (long long)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (gid >= (long long)g.T * c4n) return;
     const int t = (int)(gid / c4n);
     const int c = (int)(gid - (long long)t * c4n) * 4;
@@ -191,14 +206,14 @@ __global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restric
             f32x4 s = zero;
 #pragma unroll
             for (int j = 0; j < WN; ++j)
-                if (kBT[b][j] != 0.f) s += kBT[b][j] * dd[j];
+                if (cBT<WM>(b, j) != 0.f) s += cBT<WM>(b, j) * dd[j];
             r[b] = s;
         }
 #pragma unroll
         for (int a = 0; a < WN; ++a)
-            if (kBT[a][i] != 0.f) {
+            if (cBT<WM>(a, i) != 0.f) {
 #pragma unroll
-                for (int b = 0; b < WN; ++b) acc[a][b] += kBT[a][i] * r[b];
+                for (int b = 0; b < WN; ++b) acc[a][b] += cBT<WM>(a, i) * r[b];
             }
     }
     const size_t plane = (size_t)g.T * C;
@@ -217,12 +232,13 @@ __global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restric
 // A workgroup owns TB tiles x cl4 channel quads and leaves one [2][K] partial row per blockIdx.x.
 constexpr int TB = 8;
 
-template <bool FRONT>
+template <int WM, bool FRONT>
 __global__ __launch_bounds__(256) void wino3_output_kernel(const float* __restrict__ m, const float* __restrict__ bias,
                                                      float* __restrict__ y, const float* __restrict__ relu_src,
                                                      const float* __restrict__ bn_y, const float* __restrict__ bn_mean,
                                                      const float* __restrict__ bn_invstd, float* __restrict__ stat_part,
                                                      const float* __restrict__ addend, int act, Geom g, int K, int cl4) {
+    constexpr int WN = WM + 2;
     __shared__ f32x4 red[2][256];
     const int tid = threadIdx.x;
     const int lane_c = tid % cl4, lane_t = tid / cl4;
@@ -237,6 +253,8 @@ __global__ __launch_bounds__(256) void wino3_output_kernel(const float* __restri
         mu = *reinterpret_cast<const f32x4*>(bn_mean + k);
         is = *reinterpret_cast<const f32x4*>(bn_invstd + k);
     }
+    // (F(4x4): the scheduler issues all 36 plane loads first - 300 registers, one wave per SIMD, 147 KB in flight per CU:
+    // what an HBM-bound gather wants.  A 256-register bound spills 50 of them to scratch and is slower.)
     f32x4 s4 = zero, q4 = zero;
     for (int tt = lane_t; tt < TB; tt += tpi_iter) {
         const int t = t0 + tt;
@@ -260,14 +278,14 @@ __global__ __launch_bounds__(256) void wino3_output_kernel(const float* __restri
                 f32x4 s = zero;
 #pragma unroll
                 for (int b = 0; b < WN; ++b)
-                    if (kAT[j][b] != 0.f) s += kAT[j][b] * mm[b];
+                    if (cAT<WM>(j, b) != 0.f) s += cAT<WM>(j, b) * mm[b];
                 p[j] = s;
             }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-                if (kAT[i][a] != 0.f) {
+                if (cAT<WM>(i, a) != 0.f) {
 #pragma unroll
-                    for (int j = 0; j < WM; ++j) yy[i][j] += kAT[i][a] * p[j];
+                    for (int j = 0; j < WM; ++j) yy[i][j] += cAT<WM>(i, a) * p[j];
                 }
         }
 #pragma unroll
@@ -319,7 +337,9 @@ __global__ __launch_bounds__(256) void wino3_output_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------ weight gradient
 // dM = A dY A^T (A = (A^T)^T, 5x3), dU[xi] = dM[xi]^T V[xi] (vspw_bmm_tn, batch 25), dg = G^T dU G.
 // Output pixels outside the image (ragged tiles) carry no gradient.
+template <int WM>
 __global__ __launch_bounds__(256) void wino3_dy_kernel(const float* __restrict__ dy, float* __restrict__ dm, Geom g, int K) {
+    constexpr int WN = WM + 2;
     const int k4n = K >> 2;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long long)g.T * k4n) return;
@@ -349,14 +369,14 @@ __global__ __launch_bounds__(256) void wino3_dy_kernel(const float* __restrict__
             f32x4 s = zero;
 #pragma unroll
             for (int j = 0; j < WM; ++j)
-                if (kAT[j][b] != 0.f) s += kAT[j][b] * d[j];
+                if (cAT<WM>(j, b) != 0.f) s += cAT<WM>(j, b) * d[j];
             r[b] = s;
         }
 #pragma unroll
         for (int a = 0; a < WN; ++a)
-            if (kAT[i][a] != 0.f) {
+            if (cAT<WM>(i, a) != 0.f) {
 #pragma unroll
-                for (int b = 0; b < WN; ++b) acc[a][b] += kAT[i][a] * r[b];
+                for (int b = 0; b < WN; ++b) acc[a][b] += cAT<WM>(i, a) * r[b];
             }
     }
     const size_t plane = (size_t)g.T * K;
@@ -368,7 +388,9 @@ __global__ __launch_bounds__(256) void wino3_dy_kernel(const float* __restrict__
 }
 
 // dW[k][ky][kx][c] = (G^T dU G)[ky][kx]; dU [25][K][C]; one thread per (k, c), fp64 arithmetic
+template <int WM>
 __global__ __launch_bounds__(256) void wino3_dw_kernel(const float* __restrict__ du, float* __restrict__ dw, int K, int C) {
+    constexpr int WN = WM + 2;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long long)K * C) return;
     const int k = (int)(gid / C);
@@ -387,7 +409,7 @@ __global__ __launch_bounds__(256) void wino3_dw_kernel(const float* __restrict__
             const double u = (double)in[(size_t)(a * WN + b) * plane];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                if (kG[a][i] != 0.) t[i][b] += kG[a][i] * u;
+                if (cG<WM>(a, i) != 0.) t[i][b] += cG<WM>(a, i) * u;
         }
     float* out = dw + (size_t)k * 9 * C + c;
 #pragma unroll
@@ -397,7 +419,7 @@ __global__ __launch_bounds__(256) void wino3_dw_kernel(const float* __restrict__
             double s = 0.;
 #pragma unroll
             for (int b = 0; b < WN; ++b)
-                if (kG[b][j] != 0.) s += t[i][b] * kG[b][j];
+                if (cG<WM>(b, j) != 0.) s += t[i][b] * cG<WM>(b, j);
             out[(size_t)(i * 3 + j) * C] = (float)s;
         }
 }
@@ -411,78 +433,107 @@ static int cl4_of(int K) {
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
-extern "C" size_t vspw_wino3_supported(const vspw_conv_desc* d) {
+// vspw_wino3_* = F(3x3,3x3), vspw_wino4_* = F(4x4,3x3): the same nine calls (25 / 36 planes).
+template <int WM>
+static size_t t_supported(const vspw_conv_desc* d) {
     Geom g;
-    if (!geom(d, g)) return 0;
+    if (!geom<WM>(d, g)) return 0;
     if (d->c % 32 != 0 || d->k % 32 != 0) return 0;  // vector gathers + the v2 GEMM kernel on both sides
     return (cl4_of(d->k) && cl4_of(d->c)) ? 1 : 0;
 }
-
-extern "C" long long vspw_wino3_tiles(const vspw_conv_desc* d) {
+template <int WM>
+static long long t_tiles(const vspw_conv_desc* d) {
     Geom g;
-    return geom(d, g) ? g.T : 0;
+    return geom<WM>(d, g) ? g.T : 0;
 }
-
-extern "C" size_t vspw_wino3_stat_partials(const vspw_conv_desc* d) {
-    Geom g;
-    return geom(d, g) ? (size_t)vspw_cdiv(g.T, TB) : 0;
-}
-
-extern "C" int vspw_wino3_weights(const float* w, float* u, int k, int c, int data_gradient, void* stream) {
+template <int WM>
+static int t_weights(const float* w, float* u, int k, int c, int data_gradient, void* stream) {
     if (!w || !u || k <= 0 || c <= 0) return VSPW_EINVAL;
-    hipLaunchKernelGGL(wino3_weight_kernel, dim3(vspw_cdiv(c, 32), vspw_cdiv(k, 32)), dim3(256), 0, vspw_stream(stream), w, u, k,
-                       c, data_gradient ? 1 : 0);
+    hipLaunchKernelGGL(wino3_weight_kernel<WM>, dim3(vspw_cdiv(c, 32), vspw_cdiv(k, 32)), dim3(256), 0, vspw_stream(stream),
+                       w, u, k, c, data_gradient ? 1 : 0);
     return vspw_launch_status();
 }
-
-extern "C" int vspw_wino3_weights_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream) {
+template <int WM>
+static int t_weights_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream) {
     if (!entries || n_entries <= 0 || total_tiles <= 0 || total_tiles > 0x7fffffffLL) return VSPW_EINVAL;
-    hipLaunchKernelGGL(wino3_weight_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, vspw_stream(stream), entries,
+    hipLaunchKernelGGL(wino3_weight_multi_kernel<WM>, dim3((unsigned)total_tiles), dim3(256), 0, vspw_stream(stream), entries,
                        n_entries);
     return vspw_launch_status();
 }
-
-extern "C" int vspw_wino3_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream) {
+template <int WM>
+static int t_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream) {
     Geom g;
-    if (!geom(d, g) || !x || !v || channels <= 0 || channels % 4) return VSPW_EINVAL;
+    if (!geom<WM>(d, g) || !x || !v || channels <= 0 || channels % 4) return VSPW_EINVAL;
     const long long items = (long long)g.T * (channels / 4);
-    hipLaunchKernelGGL(wino3_input_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), x, v, g,
-                       channels);
+    hipLaunchKernelGGL(wino3_input_kernel<WM>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), x,
+                       v, g, channels);
     return vspw_launch_status();
 }
-
-extern "C" int vspw_wino3_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
-                                 const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
-                                 float* stat_part, const float* addend, int act, void* stream) {
+template <int WM>
+static int t_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
+                    const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
+                    float* stat_part, const float* addend, int act, void* stream) {
     Geom g;
     const int cl4 = cl4_of(channels);
     if (act != 0 && act != 1) return VSPW_EINVAL;
     if (relu_src != nullptr && (addend != nullptr || act != 0)) return VSPW_EINVAL;
-    if (!geom(d, g) || !m || !y || cl4 == 0) return VSPW_EINVAL;
+    if (!geom<WM>(d, g) || !m || !y || cl4 == 0) return VSPW_EINVAL;
     const bool front = relu_src != nullptr;
     if (front && (!bn_y || !bn_mean || !bn_invstd || !stat_part)) return VSPW_EINVAL;
     const dim3 grid(vspw_cdiv(g.T, TB), channels / 4 / cl4);
     if (front)
-        hipLaunchKernelGGL(wino3_output_kernel<true>, grid, dim3(256), 0, vspw_stream(stream), m, bias, y, relu_src, bn_y, bn_mean,
-                           bn_invstd, stat_part, nullptr, 0, g, channels, cl4);
+        hipLaunchKernelGGL((wino3_output_kernel<WM, true>), grid, dim3(256), 0, vspw_stream(stream), m, bias, y, relu_src,
+                           bn_y, bn_mean, bn_invstd, stat_part, nullptr, 0, g, channels, cl4);
     else
-        hipLaunchKernelGGL(wino3_output_kernel<false>, grid, dim3(256), 0, vspw_stream(stream), m, bias, y, nullptr, nullptr,
-                           nullptr, nullptr, stat_part, addend, act, g, channels, cl4);
+        hipLaunchKernelGGL((wino3_output_kernel<WM, false>), grid, dim3(256), 0, vspw_stream(stream), m, bias, y, nullptr,
+                           nullptr, nullptr, nullptr, stat_part, addend, act, g, channels, cl4);
     return vspw_launch_status();
 }
-
-extern "C" int vspw_wino3_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream) {
+template <int WM>
+static int t_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream) {
     Geom g;
-    if (!geom(d, g) || !dy || !dm || channels <= 0 || channels % 4) return VSPW_EINVAL;
+    if (!geom<WM>(d, g) || !dy || !dm || channels <= 0 || channels % 4) return VSPW_EINVAL;
     const long long items = (long long)g.T * (channels / 4);
-    hipLaunchKernelGGL(wino3_dy_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), dy, dm, g,
-                       channels);
+    hipLaunchKernelGGL(wino3_dy_kernel<WM>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), dy, dm,
+                       g, channels);
     return vspw_launch_status();
 }
-
-extern "C" int vspw_wino3_dw(const float* du, float* dw, int k, int c, void* stream) {
+template <int WM>
+static int t_dw(const float* du, float* dw, int k, int c, void* stream) {
     if (!du || !dw || k <= 0 || c <= 0) return VSPW_EINVAL;
     const long long items = (long long)k * c;
-    hipLaunchKernelGGL(wino3_dw_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), du, dw, k, c);
+    hipLaunchKernelGGL(wino3_dw_kernel<WM>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), du, dw,
+                       k, c);
     return vspw_launch_status();
 }
+
+#define VSPW_WINO_M(NAME, WM)                                                                                              \
+    extern "C" size_t vspw_##NAME##_supported(const vspw_conv_desc* d) { return t_supported<WM>(d); }                      \
+    extern "C" long long vspw_##NAME##_tiles(const vspw_conv_desc* d) { return t_tiles<WM>(d); }                            \
+    extern "C" size_t vspw_##NAME##_stat_partials(const vspw_conv_desc* d) {                                                \
+        const long long t = t_tiles<WM>(d);                                                                                 \
+        return t ? (size_t)vspw_cdiv(t, TB) : 0;                                                                            \
+    }                                                                                                                       \
+    extern "C" int vspw_##NAME##_weights(const float* w, float* u, int k, int c, int data_gradient, void* stream) {         \
+        return t_weights<WM>(w, u, k, c, data_gradient, stream);                                                            \
+    }                                                                                                                       \
+    extern "C" int vspw_##NAME##_weights_multi(const vspw_wt_entry* e, int n, long long tiles, void* stream) {              \
+        return t_weights_multi<WM>(e, n, tiles, stream);                                                                    \
+    }                                                                                                                       \
+    extern "C" int vspw_##NAME##_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream) {     \
+        return t_input<WM>(d, x, channels, v, stream);                                                                      \
+    }                                                                                                                       \
+    extern "C" int vspw_##NAME##_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y, \
+                                        const float* relu_src, const float* bn_y, const float* bn_mean,                     \
+                                        const float* bn_invstd, float* stat_part, const float* addend, int act,             \
+                                        void* stream) {                                                                     \
+        return t_output<WM>(d, m, channels, bias, y, relu_src, bn_y, bn_mean, bn_invstd, stat_part, addend, act, stream);   \
+    }                                                                                                                       \
+    extern "C" int vspw_##NAME##_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream) {      \
+        return t_dy<WM>(d, dy, channels, dm, stream);                                                                       \
+    }                                                                                                                       \
+    extern "C" int vspw_##NAME##_dw(const float* du, float* dw, int k, int c, void* stream) {                               \
+        return t_dw<WM>(du, dw, k, c, stream);                                                                              \
+    }
+VSPW_WINO_M(wino3, 3)
+VSPW_WINO_M(wino4, 4)

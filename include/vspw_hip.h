@@ -258,6 +258,20 @@ int vspw_wino3_output(const vspw_conv_desc* d, const float* m, int channels, con
                       float* stat_part, const float* addend, int act, void* stream);
 int vspw_wino3_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream);
 int vspw_wino3_dw(const float* du, float* dw, int k, int c, void* stream);
+/* F(4x4,3x3): the same nine calls over 4x4 output tiles / 6x6 patches (points 0, 1, -1, 1/2, -2, inf), 36 planes: 36/144 of
+ * the direct multiplications where 4 divides the sub-grid edge (the undilated 60x60 shapes), 36/126.6 after padding 30 ->
+ * 32 / 15 -> 16 on the dilated ones.  Conv-level rounding error as F(3x3) with this point set (winograd_f3.hip). */
+size_t vspw_wino4_supported(const vspw_conv_desc* d);
+long long vspw_wino4_tiles(const vspw_conv_desc* d);
+size_t vspw_wino4_stat_partials(const vspw_conv_desc* d);
+int vspw_wino4_weights(const float* w, float* u, int k, int c, int data_gradient, void* stream);
+int vspw_wino4_weights_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream);
+int vspw_wino4_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream);
+int vspw_wino4_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
+                      const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
+                      float* stat_part, const float* addend, int act, void* stream);
+int vspw_wino4_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream);
+int vspw_wino4_dw(const float* du, float* dw, int k, int c, void* stream);
 
 /* ---------------------------------------------------------------- batch norm (bn.hip) ------------- */
 /* Replaces SynchronizedBatchNorm2d.forward = F.batch_norm (models/sync_batchnorm/batchnorm.py:68-98) and its

@@ -79,7 +79,8 @@ def wino_rows_tile(request):
     from cvpr2021_vspw_implement_amd import _C, ops
 
     _C.call("vspw_wino_rows_config", max(int(request.param), 0))
-    prev = ops.set_winograd_f3(int(request.param) == -3)  # -3: F(3x3,3x3) instead (no row-fused form)
+    # -3 / -4: F(3x3,3x3) / F(4x4,3x3) instead (no row-fused form)
+    prev = ops.set_winograd_f3(-int(request.param) if int(request.param) < 0 else False)
     yield int(request.param)
     ops.set_winograd_f3(prev)
     _C.call("vspw_wino_rows_config", 0)
@@ -87,11 +88,12 @@ def wino_rows_tile(request):
 
 @pytest.fixture
 def wino_f3(request):
-    """Tile size of the Winograd path: F(3x3,3x3) (csrc/winograd_f3.hip, True) or F(2x2,3x3) (csrc/winograd.hip)."""
+    """Tile size of the Winograd path: False = F(2x2,3x3) (csrc/winograd.hip), 3 / 4 = F(3x3,3x3) / F(4x4,3x3) forced
+    (csrc/winograd_f3.hip), True = the automatic choice."""
     from cvpr2021_vspw_implement_amd import ops
 
-    prev = ops.set_winograd_f3(bool(request.param))
-    yield bool(request.param)
+    prev = ops.set_winograd_f3(request.param)
+    yield request.param
     ops.set_winograd_f3(prev)
 
 
@@ -101,19 +103,24 @@ WINO_CASES = [c for c in CONV_CASES if c[5] == 3 and c[6] == 1 and min(c[1], c[4
     (1, 256, 15, 30, 128, 3, 1, 4, 4, True),
     (2, 128, 7, 11, 160, 3, 1, 1, 1, False),
     (1, 160, 20, 9, 128, 3, 1, 2, 2, False),
+    (2, 128, 16, 24, 128, 3, 1, 1, 1, True),   # exact 4x4 tiling
 ]
 
 
-@pytest.mark.parametrize("wino_f3", [False, True], indirect=True)
+@pytest.mark.parametrize("wino_f3", [False, 3, 4, True], indirect=True)
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_conv2d_winograd_tile_sizes(dev, case, wino_f3):
-    """The parity gate of test_conv2d_fwd_bwd (against F.conv2d on the CPU) for both Winograd tile sizes, all three
-    passes; checks that the F(3x3) launches happened when asked for."""
+    """The parity gate of test_conv2d_fwd_bwd (against F.conv2d on the CPU) for every Winograd tile size, all three
+    passes (ragged tiles, dilation sub-grids); checks that the F(3x3) / F(4x4) launches happened when asked for."""
     from cvpr2021_vspw_implement_amd import ops
 
-    before = ops._wino["f3_launches"]
+    before = (ops._wino["f3_launches"], ops._wino["f4_launches"])
     test_conv2d_fwd_bwd(dev, case)
-    assert (ops._wino["f3_launches"] - before) == (3 if wino_f3 else 0)
+    got = (ops._wino["f3_launches"] - before[0], ops._wino["f4_launches"] - before[1])
+    if wino_f3 is True:
+        assert sum(got) == 3 and 0 in got  # one tile size for all three passes
+    else:
+        assert got == {False: (0, 0), 3: (3, 0), 4: (0, 3)}[wino_f3]
 
 
 @pytest.mark.parametrize("wino_rows_tile", [12, 31, 22], indirect=True)
@@ -130,7 +137,7 @@ def test_conv2d_winograd_row_fused_form(dev, case, wino_rows_tile):
     test_conv2d_fwd_bwd(dev, case)
 
 
-@pytest.mark.parametrize("wino_rows_tile", [0, 12, 31, -3], indirect=True)
+@pytest.mark.parametrize("wino_rows_tile", [0, 12, 31, -3, -4], indirect=True)
 @pytest.mark.parametrize("dil,h,w", [(1, 12, 13), (2, 14, 14), (4, 15, 15)])
 def test_winograd_path_equals_direct_path_in_a_fused_chain(dev, dil, h, w, wino_rows_tile):
     """1x1 conv+BN+ReLU -> 3x3 conv+BN+ReLU (fuse_input: the 3x3 data gradient carries the first node's BatchNorm-backward

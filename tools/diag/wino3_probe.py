@@ -19,7 +19,7 @@ SHAPES = [  # name, n, h, w, cin, cout, dil, launches per step (fwd = dgrad = wg
     ("l3.0 256->256 d1", 10, 60, 60, 256, 256, 1, 1),
     ("l4 512->512 d4", 10, 60, 60, 512, 512, 4, 2),
     ("l4.0 512->512 d2", 10, 60, 60, 512, 512, 2, 1),
-    ("deepsup 1024->256 d1", 10, 60, 60, 1024, 256, 1, 1),
+    ("deepsup 1024->512 d1", 10, 60, 60, 1024, 512, 1, 1),
     ("conv_last 4096->512 n2", 2, 60, 60, 4096, 512, 1, 1),
     ("l2 128->128 d1", 10, 60, 60, 128, 128, 1, 3),
 ]
@@ -49,7 +49,7 @@ def main():
     ops.set_wgrad_side_stream(False)
     print("%-24s %-8s %9s %9s %9s %9s   %s" % ("shape", "tile", "fwd us", "dgrad us", "wgrad us", "sum us", "rel diff of (y, dx, dw) vs F(2x2)"))
     saved = {}
-    total = {False: 0.0, True: 0.0}
+    total = {False: 0.0, 3: 0.0, 4: 0.0}
     for name, n, h, w, c, k, dil, per_step in SHAPES:
         if flt and flt not in name:
             continue
@@ -58,7 +58,7 @@ def main():
         zs = [ops.empty_nhwc(n, c, h, w, dev).normal_() for _ in range(SETS)]   # ReLU source / BN y of the producer
         wt = (torch.randn(k, c, 3, 3, device=dev) * (2.0 / (9 * c)) ** 0.5).contiguous(memory_format=torch.channels_last)
         mean, invstd = torch.zeros(c, device=dev), torch.ones(c, device=dev)
-        for f3 in (False, True):
+        for f3 in (False, 3, 4):
             ops.set_winograd_f3(f3)
             outs = {}
 
@@ -89,11 +89,11 @@ def main():
             else:
                 saved[name] = res
             total[f3] += per_step * (tf + td + tw)
-            print("%-24s %-8s %9.1f %9.1f %9.1f %9.1f   %s" % (name, "F(3x3)" if f3 else "F(2x2)", tf, td, tw, tf + td + tw, diff), flush=True)
+            print("%-24s %-8s %9.1f %9.1f %9.1f %9.1f   %s" % (name, "F(%dx%d)" % (f3 or 2, f3 or 2), tf, td, tw, tf + td + tw, diff), flush=True)
             outs.clear()
         del xs, dys, zs
         torch.cuda.empty_cache()
-    print("per step (launch counts of TCB-PSP R101): F(2x2) %.2f ms, F(3x3) %.2f ms" % (total[False] / 1e3, total[True] / 1e3))
+    print("per step (launch counts of TCB-PSP R101): F(2x2) %.2f ms, F(3x3) %.2f ms, F(4x4) %.2f ms" % (total[False] / 1e3, total[3] / 1e3, total[4] / 1e3))
 
 
 if __name__ == "__main__":

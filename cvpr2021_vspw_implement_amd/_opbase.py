@@ -113,10 +113,6 @@ _HBM_BYTES = {
     "vspw_wino3_input": lambda a: _wino_bytes(a, 2, 1, planes=25.0),
     "vspw_wino3_dy": lambda a: _wino_bytes(a, 2, 1, planes=25.0),
     "vspw_wino3_output": lambda a: _wino_bytes(a, 2, 1 + _nn(a[5], a[6], a[10]), planes=25.0),
-    "vspw_wino3_input_aff": lambda a: _wino_bytes(a, 4, 2, planes=25.0),
-    "vspw_wino3_dy_aff": lambda a: _wino_bytes(a, 4, 2, planes=25.0),
-    "vspw_wino4_input_aff": lambda a: _wino_bytes(a, 4, 2, planes=36.0),
-    "vspw_wino4_dy_aff": lambda a: _wino_bytes(a, 4, 2, planes=36.0),
     # F(4x4,3x3): 36 planes
     "vspw_wino4_input": lambda a: _wino_bytes(a, 2, 1, planes=36.0),
     "vspw_wino4_dy": lambda a: _wino_bytes(a, 2, 1, planes=36.0),

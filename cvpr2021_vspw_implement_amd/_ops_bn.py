@@ -10,7 +10,7 @@ from . import _C
 from ._C import ConvDesc
 from ._opbase import (_Timed, _conv_desc, _conv_flops, _conv_tag, _p, _require_gpu, _stream, _ws, empty_nhwc, is_nhwc,
                       to_nhwc)
-from ._ops_conv import (_fwd_apply, _wino, _wino3_conv, _wino_aff_ok, _wino_conv, _wino_f3, _wino_ok, _wino_takes_pending, _wt_cache, colsum,
+from ._ops_conv import (_fwd_apply, _wino, _wino3_conv, _wino_conv, _wino_f3, _wino_ok, _wino_takes_pending, _wt_cache, colsum,
                         conv2d_backward_data, conv2d_backward_weight, conv2d_forward)
 
 # --------------------------------------------------------------------------------------------------- batch norm
@@ -295,7 +295,6 @@ class BNLink(object):
 
 _bn_fusion = {"enabled": os.environ.get("VSPW_NO_BN_FUSION", "0") != "1", "fused_nodes": 0,
               "affine": os.environ.get("VSPW_NO_BN_AFFINE", "0") != "1", "affine_nodes": 0,
-              "affine_wino": os.environ.get("VSPW_NO_BN_AFFINE_WINO", "0") != "1", "affine_wino_nodes": 0,
               # narrow outputs (conv1 of a bottleneck: dy is 1/4 the size of its input gradient) gain nothing: the pass
               # saved is as cheap as the second operand stream it costs (measured: 256 ch +-0, 1024 ch -70 us / block)
               "affine_min_c": int(os.environ.get("VSPW_AFFINE_MINC", "512"))}
@@ -433,12 +432,6 @@ class ConvBNActFn(torch.autograd.Function):
             pointwise = d.kh == 1 and d.kw == 1 and d.stride == 1 and d.pad == 0 and d.pad_w == 0
             affine = (_bn_fusion["affine"] and pointwise and not ctx.has_cbias and c >= _bn_fusion["affine_min_c"]
                       and _C.query("vspw_conv2d_bwd_aff_supported", ctypes.byref(d)) == 1)
-            # ... and of a stride-1 3x3 conv by the F(3x3) / F(4x4) transforms of its two gradients (round 6): the input
-            # transform of the data gradient and the dY transform of the weight gradient evaluate it per patch pixel
-            if not affine and _bn_fusion["affine"] and _bn_fusion["affine_wino"] and not ctx.has_cbias and _wino_aff_ok(d) \
-                    and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]:
-                affine = True
-                _bn_fusion["affine_wino_nodes"] += 1
             exchange = ctx.training and ctx.world != 1
             if affine and not exchange:  # reduction and coefficients in one launch (nothing to exchange in between)
                 coef = torch.empty((3, c), device=dev, dtype=torch.float32)

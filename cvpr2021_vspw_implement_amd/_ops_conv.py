@@ -113,10 +113,9 @@ def _wino_f3(d):
 
 
 def _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, part=None, what="fwd", u=None,
-                addend=None, act=0, m=None, aff=None):
+                addend=None, act=0, m=None):
     """_wino_conv through F(m x m, 3x3), m = 3 or 4: input transform, (m+2)^2 batched GEMMs, output transform
-    (winograd_f3.hip).  aff = (y, coef): src is g, the gradient w.r.t. the BatchNorm output; the input transform evaluates
-    coef[0]*g + coef[1]*y + coef[2] (BatchNorm's backward apply) per patch pixel (data gradient only)."""
+    (winograd_f3.hip)."""
     dev, st = src.device, _stream()
     m = m or _wino_f3(d)
     P, api = (m + 2) * (m + 2), "vspw_wino%d_" % m
@@ -124,10 +123,7 @@ def _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None,
     if u is None:
         u = _wino3_weights(w, data_gradient, m)
     v = torch.empty((P, T, reduce_c), device=dev, dtype=torch.float32)
-    if aff is not None:
-        _C.call(api + "input_aff", ctypes.byref(d), _p(src), _p(aff[0]), _p(aff[1]), reduce_c, _p(v), st)
-    else:
-        _C.call(api + "input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
+    _C.call(api + "input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
     mm = torch.empty((P, T, rows), device=dev, dtype=torch.float32)
     with _Timed("igemm_nt_kernel", 2.0 * P * T * rows * reduce_c, _conv_tag(d, what + "-wino%d" % m), _conv_flops(d)):
         _C.call("vspw_bmm_nt", _p(v), _p(u), _p(mm), P, T, rows, reduce_c, st)
@@ -142,14 +138,12 @@ def _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None,
 
 
 def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, part=None, what="fwd", u=None,
-               addend=None, act=0, fuse=None, pending=None, aff=None):
+               addend=None, act=0, fuse=None, pending=None):
     """dst = conv(src) through U, V, M (see winograd.hip); rows = output channels, reduce_c = channels of src.
     u: transformed weights supplied by the caller (inference: of the BatchNorm-folded weights).
     pending = (y_prev, scale_shift): src has not been written - the input transform evaluates it (see _fwd_apply)."""
     if pending is None and u is None and _wino_f3(d):
-        return _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front, part, what, None, addend, act, aff=aff)
-    if aff is not None:
-        raise RuntimeError("affine dY operand: F(3x3) / F(4x4) input transform only (see _wino_aff_ok)")
+        return _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front, part, what, None, addend, act)
     dev = src.device
     st = _stream()
     T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
@@ -198,12 +192,6 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
                 _p(part), _p(addend), act, st)
     _wino["launches"] += 1
     return v
-
-
-def _wino_aff_ok(d):
-    """BatchNorm's backward apply of a stride-1 3x3 conv + BN node can be left to the two gradient transforms of its
-    convolution (vspw_wino{3,4}_input_aff / _dy_aff): both gradients go through F(3x3) / F(4x4)."""
-    return _wino_ok(d) and _wino["wgrad"] and _wino_f3(d) != 0 and d.c % 4 == 0 and d.k % 4 == 0
 
 
 def _wino_takes_pending(d, pending, wgrad):
@@ -425,7 +413,7 @@ def conv2d_backward_data(dy, w, d, addend=None, bn_front=None, aff=None):
     coef[0]*g + coef[1]*y + coef[2] (BatchNorm's backward apply) as its operand (pointwise convs only)."""
     k, c, kh, kw = w.shape
     dx = empty_nhwc(d.n, d.c, d.h, d.w, dy.device)
-    if addend is None and _wino_ok(d) and (aff is None or _wino_aff_ok(d)):
+    if aff is None and addend is None and _wino_ok(d):
         front = part = None
         if bn_front is not None:
             z, link = bn_front
@@ -433,7 +421,7 @@ def conv2d_backward_data(dy, w, d, addend=None, bn_front=None, aff=None):
             fm = _wino_f3(d)
             part = torch.empty((_C.query(("vspw_wino%d_stat_partials" % fm) if fm else "vspw_wino_stat_partials",
                                          ctypes.byref(d)), 2, d.c), device=dy.device, dtype=torch.float32)
-        _wino_conv(d, dy, w, d.c, d.k, True, None, dx, front=front, part=part, what="dgrad", aff=aff)
+        _wino_conv(d, dy, w, d.c, d.k, True, None, dx, front=front, part=part, what="dgrad")
         if bn_front is not None:
             link.partials, link.g = part, dx
         return dx
@@ -509,7 +497,7 @@ def join_side_streams():
         _wgrad_side["dirty"] = False
 
 
-def _wino_wgrad(dy, x, d, dw, v=None, aff=None):
+def _wino_wgrad(dy, x, d, dw, v=None):
     """dW of a stride-1 3x3 convolution in the Winograd domain (see winograd.hip): 4/9 of the direct multiplications.
     v: the input transform kept by the forward pass (recomputed from x when absent)."""
     dev, st = dy.device, _stream()
@@ -521,10 +509,7 @@ def _wino_wgrad(dy, x, d, dw, v=None, aff=None):
             v = torch.empty((P, T, d.c), device=dev, dtype=torch.float32)
             _C.call(api + "input", ctypes.byref(d), _p(x), d.c, _p(v), st)
         dm = torch.empty((P, T, d.k), device=dev, dtype=torch.float32)
-        if aff is not None:  # dy is g: BatchNorm's backward apply evaluated by the transform (see _wino3_conv)
-            _C.call(api + "dy_aff", ctypes.byref(d), _p(dy), _p(aff[0]), _p(aff[1]), d.k, _p(dm), st)
-        else:
-            _C.call(api + "dy", ctypes.byref(d), _p(dy), d.k, _p(dm), st)
+        _C.call(api + "dy", ctypes.byref(d), _p(dy), d.k, _p(dm), st)
         du = torch.empty((P, d.k, d.c), device=dev, dtype=torch.float32)
         nbytes = _C.query("vspw_bmm_tn_workspace", P, T, d.k, d.c)
         ws = _ws(nbytes, dev) if nbytes else None
@@ -534,8 +519,6 @@ def _wino_wgrad(dy, x, d, dw, v=None, aff=None):
         _wino["launches"] += 1
         _wino["f%d_launches" % fm] += 1
         return
-    if aff is not None:
-        raise RuntimeError("affine dY operand: F(3x3) / F(4x4) transforms only (see _wino_aff_ok)")
     T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
     if v is None or tuple(v.shape) != (16, T, d.c):
         v = torch.empty((16, T, d.c), device=dev, dtype=torch.float32)
@@ -553,8 +536,8 @@ def _wino_wgrad(dy, x, d, dw, v=None, aff=None):
 
 def _wgrad_launch(dy, x, d, aff=None, wino_v=None):
     dw = torch.empty((d.k, d.kh, d.kw, d.c), device=dy.device, dtype=torch.float32).permute(0, 3, 1, 2)
-    if _wino["wgrad"] and _wino_ok(d) and (aff is None or _wino_aff_ok(d)):
-        _wino_wgrad(dy, x, d, dw, wino_v, aff)
+    if aff is None and _wino["wgrad"] and _wino_ok(d):
+        _wino_wgrad(dy, x, d, dw, wino_v)
         return dw, None
     nbytes = _C.query("vspw_conv2d_bwd_weight_workspace", ctypes.byref(d))
     ws = _ws(nbytes, dy.device) if nbytes else None

@@ -169,13 +169,8 @@ __global__ __launch_bounds__(256) void wino3_weight_multi_kernel(const vspw_wt_e
 // ------------------------------------------------------------------------------------------------ input
 // V[xi][t][c] = (B^T d B)[xi].  One thread: one tile, 4 channels; patch rows are consumed as they arrive
 // (row i contributes BT[a][i] * (d[i][.] B)[b] to every V[a][b]).
-// AFF: the operand is dY = coef[0] * x + (coef[1] * x2 + coef[2]) per channel - BatchNorm's backward apply of the node this
-// convolution belongs to (x = g, the gradient w.r.t. the BatchNorm output, x2 = the pre-BatchNorm activations, coef [3][C]
-// from vspw_bn_bwd_affine_coeffs; same expression as the pointwise GEMMs' AFF operand, conv_igemm.hip) - evaluated per
-// patch pixel, zero outside the image; dY itself is never written.
-template <int WM, bool AFF>
-__global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restrict__ x, float* __restrict__ v, Geom g, int C,
-                                                          const float* __restrict__ x2, const float* __restrict__ coef) {
+template <int WM>
+__global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restrict__ x, float* __restrict__ v, Geom g, int C) {
     constexpr int WN = WM + 2;
     const int c4n = C >> 2;
     // XCD-aware order: neighbouring tiles share two of their five patch columns / rows - keep them in one L2 (measured
@@ -187,12 +182,6 @@ __global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restric
     int img, sy, sx, ty, tx;
     tile_of(g, t, img, sy, sx, ty, tx);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 cfa = zero, cfb = zero, cfc = zero;
-    if (AFF) {
-        cfa = *reinterpret_cast<const f32x4*>(coef + c);
-        cfb = *reinterpret_cast<const f32x4*>(coef + C + c);
-        cfc = *reinterpret_cast<const f32x4*>(coef + 2 * C + c);
-    }
     f32x4 acc[WN][WN];
 #pragma unroll
     for (int a = 0; a < WN; ++a)
@@ -209,12 +198,7 @@ __global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restric
             const int gx = WM * tx - 1 + j;
             const int px = gx * g.d + sx;
             const bool ok = oky & (gx >= 0) & (px < g.w);
-            const size_t e = (((size_t)img * g.h + py) * g.w + px) * C + c;
-            if (AFF)
-                dd[j] = ok ? cfa * *reinterpret_cast<const f32x4*>(x + e) + (cfb * *reinterpret_cast<const f32x4*>(x2 + e) + cfc)
-                           : zero;
-            else
-                dd[j] = ok ? *reinterpret_cast<const f32x4*>(x + e) : zero;
+            dd[j] = ok ? *reinterpret_cast<const f32x4*>(x + (((size_t)img * g.h + py) * g.w + px) * C + c) : zero;
         }
         f32x4 r[WN];
 #pragma unroll
@@ -353,10 +337,8 @@ __global__ __launch_bounds__(256) void wino3_output_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------ weight gradient
 // dM = A dY A^T (A = (A^T)^T, 5x3), dU[xi] = dM[xi]^T V[xi] (vspw_bmm_tn, batch 25), dg = G^T dU G.
 // Output pixels outside the image (ragged tiles) carry no gradient.
-// AFF: dY = coef[0] * dy + (coef[1] * y2 + coef[2]) as in wino3_input_kernel.
-template <int WM, bool AFF>
-__global__ __launch_bounds__(256) void wino3_dy_kernel(const float* __restrict__ dy, float* __restrict__ dm, Geom g, int K,
-                                                       const float* __restrict__ y2, const float* __restrict__ coef) {
+template <int WM>
+__global__ __launch_bounds__(256) void wino3_dy_kernel(const float* __restrict__ dy, float* __restrict__ dm, Geom g, int K) {
     constexpr int WN = WM + 2;
     const int k4n = K >> 2;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -366,12 +348,6 @@ __global__ __launch_bounds__(256) void wino3_dy_kernel(const float* __restrict__
     int img, sy, sx, ty, tx;
     tile_of(g, t, img, sy, sx, ty, tx);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 cfa = zero, cfb = zero, cfc = zero;
-    if (AFF) {
-        cfa = *reinterpret_cast<const f32x4*>(coef + k);
-        cfb = *reinterpret_cast<const f32x4*>(coef + K + k);
-        cfc = *reinterpret_cast<const f32x4*>(coef + 2 * K + k);
-    }
     f32x4 acc[WN][WN];
 #pragma unroll
     for (int a = 0; a < WN; ++a)
@@ -384,13 +360,8 @@ __global__ __launch_bounds__(256) void wino3_dy_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < WM; ++j) {
             const int ox = (WM * tx + j) * g.d + sx;
-            const bool ok = oy < g.h && ox < g.w;
-            const size_t e = (((size_t)img * g.h + oy) * g.w + ox) * K + k;
-            if (AFF)
-                d[j] = ok ? cfa * *reinterpret_cast<const f32x4*>(dy + e) + (cfb * *reinterpret_cast<const f32x4*>(y2 + e) + cfc)
-                          : zero;
-            else
-                d[j] = ok ? *reinterpret_cast<const f32x4*>(dy + e) : zero;
+            d[j] = (oy < g.h && ox < g.w) ? *reinterpret_cast<const f32x4*>(dy + (((size_t)img * g.h + oy) * g.w + ox) * K + k)
+                                          : zero;
         }
         f32x4 r[WN];
 #pragma unroll
@@ -490,17 +461,12 @@ static int t_weights_multi(const vspw_wt_entry* entries, int n_entries, long lon
     return vspw_launch_status();
 }
 template <int WM>
-static int t_input(const vspw_conv_desc* d, const float* x, const float* x2, const float* coef, int channels, float* v,
-                   void* stream) {
+static int t_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream) {
     Geom g;
-    if (!geom<WM>(d, g) || !x || !v || channels <= 0 || channels % 4 || (x2 != nullptr) != (coef != nullptr)) return VSPW_EINVAL;
+    if (!geom<WM>(d, g) || !x || !v || channels <= 0 || channels % 4) return VSPW_EINVAL;
     const long long items = (long long)g.T * (channels / 4);
-    const dim3 grid((unsigned)((items + 255) / 256));
-    if (x2)
-        hipLaunchKernelGGL((wino3_input_kernel<WM, true>), grid, dim3(256), 0, vspw_stream(stream), x, v, g, channels, x2, coef);
-    else
-        hipLaunchKernelGGL((wino3_input_kernel<WM, false>), grid, dim3(256), 0, vspw_stream(stream), x, v, g, channels,
-                           nullptr, nullptr);
+    hipLaunchKernelGGL(wino3_input_kernel<WM>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), x,
+                       v, g, channels);
     return vspw_launch_status();
 }
 template <int WM>
@@ -524,17 +490,12 @@ static int t_output(const vspw_conv_desc* d, const float* m, int channels, const
     return vspw_launch_status();
 }
 template <int WM>
-static int t_dy(const vspw_conv_desc* d, const float* dy, const float* y2, const float* coef, int channels, float* dm,
-                void* stream) {
+static int t_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream) {
     Geom g;
-    if (!geom<WM>(d, g) || !dy || !dm || channels <= 0 || channels % 4 || (y2 != nullptr) != (coef != nullptr)) return VSPW_EINVAL;
+    if (!geom<WM>(d, g) || !dy || !dm || channels <= 0 || channels % 4) return VSPW_EINVAL;
     const long long items = (long long)g.T * (channels / 4);
-    const dim3 grid((unsigned)((items + 255) / 256));
-    if (y2)
-        hipLaunchKernelGGL((wino3_dy_kernel<WM, true>), grid, dim3(256), 0, vspw_stream(stream), dy, dm, g, channels, y2, coef);
-    else
-        hipLaunchKernelGGL((wino3_dy_kernel<WM, false>), grid, dim3(256), 0, vspw_stream(stream), dy, dm, g, channels, nullptr,
-                           nullptr);
+    hipLaunchKernelGGL(wino3_dy_kernel<WM>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), dy, dm,
+                       g, channels);
     return vspw_launch_status();
 }
 template <int WM>
@@ -560,15 +521,7 @@ static int t_dw(const float* du, float* dw, int k, int c, void* stream) {
         return t_weights_multi<WM>(e, n, tiles, stream);                                                                    \
     }                                                                                                                       \
     extern "C" int vspw_##NAME##_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream) {     \
-        return t_input<WM>(d, x, nullptr, nullptr, channels, v, stream);                                                    \
-    }                                                                                                                       \
-    extern "C" int vspw_##NAME##_input_aff(const vspw_conv_desc* d, const float* g, const float* y, const float* coef,      \
-                                           int channels, float* v, void* stream) {                                          \
-        return t_input<WM>(d, g, y, coef, channels, v, stream);                                                             \
-    }                                                                                                                       \
-    extern "C" int vspw_##NAME##_dy_aff(const vspw_conv_desc* d, const float* g, const float* y, const float* coef,         \
-                                        int channels, float* dm, void* stream) {                                            \
-        return t_dy<WM>(d, g, y, coef, channels, dm, stream);                                                               \
+        return t_input<WM>(d, x, channels, v, stream);                                                                      \
     }                                                                                                                       \
     extern "C" int vspw_##NAME##_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y, \
                                         const float* relu_src, const float* bn_y, const float* bn_mean,                     \
@@ -577,7 +530,7 @@ static int t_dw(const float* du, float* dw, int k, int c, void* stream) {
         return t_output<WM>(d, m, channels, bias, y, relu_src, bn_y, bn_mean, bn_invstd, stat_part, addend, act, stream);   \
     }                                                                                                                       \
     extern "C" int vspw_##NAME##_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream) {      \
-        return t_dy<WM>(d, dy, nullptr, nullptr, channels, dm, stream);                                                     \
+        return t_dy<WM>(d, dy, channels, dm, stream);                                                                       \
     }                                                                                                                       \
     extern "C" int vspw_##NAME##_dw(const float* du, float* dw, int k, int c, void* stream) {                               \
         return t_dw<WM>(du, dw, k, c, stream);                                                                              \

@@ -258,16 +258,6 @@ int vspw_wino3_output(const vspw_conv_desc* d, const float* m, int channels, con
                       float* stat_part, const float* addend, int act, void* stream);
 int vspw_wino3_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream);
 int vspw_wino3_dw(const float* du, float* dw, int k, int c, void* stream);
-/* vspw_wino3_input / vspw_wino3_dy of dY = coef[0]*g + coef[1]*y + coef[2] per channel: BatchNorm's backward apply of the
- * conv+BN node this convolution belongs to (g = gradient w.r.t. the BatchNorm output, y = the pre-BatchNorm activations,
- * coef [3][channels] from vspw_bn_bwd_affine_coeffs - the operand form of vspw_conv2d_bwd_data_aff /
- * vspw_conv2d_bwd_weight_aff), evaluated while the patch is gathered, zero outside the image: the data- and weight-gradient
- * of a stride-1 3x3 conv + BatchNorm need no vspw_bn_bwd_apply pass and dY is never written
- * (models/sync_batchnorm/batchnorm.py:68-98 backward, followed by models/resnet.py:79's convolution backward). */
-int vspw_wino3_input_aff(const vspw_conv_desc* d, const float* g, const float* y, const float* coef, int channels,
-                         float* v, void* stream);
-int vspw_wino3_dy_aff(const vspw_conv_desc* d, const float* g, const float* y, const float* coef, int channels,
-                      float* dm, void* stream);
 /* F(4x4,3x3): the same nine calls over 4x4 output tiles / 6x6 patches (points 0, 1, -1, 1/2, -2, inf), 36 planes: 36/144 of
  * the direct multiplications where 4 divides the sub-grid edge (the undilated 60x60 shapes), 36/126.6 after padding 30 ->
  * 32 / 15 -> 16 on the dilated ones.  Conv-level rounding error as F(3x3) with this point set (winograd_f3.hip). */
@@ -281,10 +271,6 @@ int vspw_wino4_output(const vspw_conv_desc* d, const float* m, int channels, con
                       const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
                       float* stat_part, const float* addend, int act, void* stream);
 int vspw_wino4_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream);
-int vspw_wino4_input_aff(const vspw_conv_desc* d, const float* g, const float* y, const float* coef, int channels,
-                         float* v, void* stream);
-int vspw_wino4_dy_aff(const vspw_conv_desc* d, const float* g, const float* y, const float* coef, int channels,
-                      float* dm, void* stream);
 int vspw_wino4_dw(const float* du, float* dw, int k, int c, void* stream);
 
 /* ---------------------------------------------------------------- batch norm (bn.hip) ------------- */

@@ -179,48 +179,6 @@ def test_winograd_path_equals_direct_path_in_a_fused_chain(dev, dil, h, w, wino_
         assert err < (2e-4 if nm in ("dbeta1", "dbeta2") else 2e-5), (nm, float(err))
 
 
-@pytest.mark.parametrize("wino_f3", [3, 4], indirect=True)
-@pytest.mark.parametrize("dil,h,w", [(1, 12, 13), (2, 14, 14), (4, 15, 15)])
-def test_bn_backward_apply_left_to_the_winograd_transforms(dev, dil, h, w, wino_f3):
-    """1x1 -> 3x3 -> 1x1 conv+BN+ReLU chain (fuse_input on both readers): the 3x3 node's BatchNorm-backward apply is
-    evaluated by the input transform of its data gradient and the dY transform of its weight gradient
-    (vspw_wino{3,4}_input_aff / _dy_aff) instead of a vspw_bn_bwd_apply pass.  Every gradient against the separate-pass
-    form (same float32 expression per element up to association), padding taps included; the fused form must have run."""
-    from cvpr2021_vspw_implement_amd import ops
-
-    g = torch.Generator().manual_seed(31 + dil)
-    n, c0, c1, c2, c3 = 2, 64, 128, 128, 96
-    x = torch.randn(n, c0, h, w, generator=g)
-    w1 = torch.randn(c1, c0, 1, 1, generator=g) * 0.2
-    w2 = torch.randn(c2, c1, 3, 3, generator=g) * 0.05
-    w3 = torch.randn(c3, c2, 1, 1, generator=g) * 0.15
-    res = []
-    for fused in (False, True):
-        ops._bn_fusion["affine_wino"] = fused
-        before = ops._bn_fusion["affine_wino_nodes"]
-        try:
-            xd = x.to(dev).requires_grad_(True)
-            ps = [t.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True) for t in (w1, w2, w3)]
-            gb = [(torch.full((c,), 1.1, device=dev, requires_grad=True), torch.full((c,), 0.05, device=dev, requires_grad=True))
-                  for c in (c1, c2, c3)]
-            st = lambda c: (torch.zeros(c, device=dev), torch.ones(c, device=dev))  # noqa: E731
-            a = ops.conv_bn_act(xd, ps[0], None, gb[0][0], gb[0][1], *st(c1), None, None, 1, 0, 1, True, 0.1, 1e-5, True)
-            b = ops.conv_bn_act(a, ps[1], None, gb[1][0], gb[1][1], *st(c2), None, None, 1, dil, dil, True, 0.1, 1e-5, True,
-                                False, True)
-            z = ops.conv_bn_act(b, ps[2], None, gb[2][0], gb[2][1], *st(c3), None, None, 1, 0, 1, True, 0.1, 1e-5, True,
-                                False, True)
-            (z * z).sum().backward()
-            ops.join_side_streams()
-            torch.cuda.synchronize()
-            res.append([t.grad.detach().float().cpu() for t in [xd] + ps + [q for pair in gb for q in pair]])
-        finally:
-            ops._bn_fusion["affine_wino"] = True
-        assert (ops._bn_fusion["affine_wino_nodes"] - before) == (1 if fused else 0)
-    for i, (a_, b_) in enumerate(zip(res[0], res[1])):
-        err = (a_ - b_).norm() / b_.norm().clamp_min(1e-12)
-        assert err < 2e-5, (i, float(err))
-
-
 @pytest.mark.parametrize("n,c,h,w,k,bias", [
     (4, 2048, 24, 32, 256, False),  # interior 96 / 128-row tiles, 8 chains of 256
     (2, 1024, 12, 13, 200, True),   # ragged rows and columns: guarded flush, bias added once

@@ -79,6 +79,9 @@ __device__ __forceinline__ void tile_of(const Geom& g, int t, int& img, int& sy,
 // U = G g G^T.  w: [K][3][3][C] (channels_last OIHW).
 // mode bit 0 (forward):        U[xi][k][c] from g = w[k, :, :, c]
 // mode bit 1 (data gradient):  U[xi][c][k] from g = w[k, 2-ky, 2-kx, c]   (rows = Cin, reduction over Cout)
+// (explicit fma: the one-tensor and the multi-tensor kernel must round identically - left to the compiler's contraction
+// choices they differed by one fp32 ulp in a few elements per tensor, and which of the two refreshed a transform depends
+// on the cache's history)
 template <int WM>
 __device__ __forceinline__ void weight_g(const float g[9], float* u) {
     constexpr int WN = WM + 2;
@@ -90,7 +93,7 @@ __device__ __forceinline__ void weight_g(const float g[9], float* u) {
             double s = 0.;
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                if (cG<WM>(a, i) != 0.) s += cG<WM>(a, i) * (double)g[i * 3 + j];
+                if (cG<WM>(a, i) != 0.) s = __builtin_fma(cG<WM>(a, i), (double)g[i * 3 + j], s);
             t[a][j] = s;
         }
 #pragma unroll
@@ -100,7 +103,7 @@ __device__ __forceinline__ void weight_g(const float g[9], float* u) {
             double s = 0.;
 #pragma unroll
             for (int j = 0; j < 3; ++j)
-                if (cG<WM>(b, j) != 0.) s += t[a][j] * cG<WM>(b, j);
+                if (cG<WM>(b, j) != 0.) s = __builtin_fma(t[a][j], cG<WM>(b, j), s);
             u[a * WN + b] = (float)s;
         }
 }
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256) void wino3_dw_kernel(const float* __restrict__
             const double u = (double)in[(size_t)(a * WN + b) * plane];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
-                if (cG<WM>(a, i) != 0.) t[i][b] += cG<WM>(a, i) * u;
+                if (cG<WM>(a, i) != 0.) t[i][b] = __builtin_fma(cG<WM>(a, i), u, t[i][b]);
         }
     float* out = dw + (size_t)k * 9 * C + c;
 #pragma unroll
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(256) void wino3_dw_kernel(const float* __restrict__
             double s = 0.;
 #pragma unroll
             for (int b = 0; b < WN; ++b)
-                if (cG<WM>(b, j) != 0.) s += t[i][b] * cG<WM>(b, j);
+                if (cG<WM>(b, j) != 0.) s = __builtin_fma(t[i][b], cG<WM>(b, j), s);
             out[(size_t)(i * 3 + j) * C] = (float)s;
         }
 }

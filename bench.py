@@ -447,7 +447,7 @@ def main():
             traffic, traffic_src = measured_traffic("igemm_nt_kernel")
             roofline = {"bound": "mfma", "kernel": "igemm_nt_kernel", "achieved": round(achieved, 2),
                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                        "what": "flops the launches EXECUTE (the Winograd F(2x2,3x3) GEMMs count their own 4/9 of the "
+                        "what": "flops the launches EXECUTE (the Winograd F(3x3,3x3) / F(4x4,3x3) GEMMs count their own 25/81 / 36/144 of the "
                                 "direct-convolution multiplications) / HIP-event time of those launches",
                         "effective_direct_conv_tflops": round(effective, 2),
                         "traffic": traffic, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, %s)" % traffic_src,
@@ -457,7 +457,7 @@ def main():
                         "gflop_per_launch": round(flops / len(recs) / 1e9, 3),
                         "share_of_step_time": round(ms * 1e-3 / len(timed_steps) / (elapsed / args.steps), 3),
                         # the same launches priced at the direct-convolution FLOPs they replace (SURVEY 8(d)'s algorithmic
-                        # count): can exceed 1 because Winograd executes 4/9 of the 3x3 multiplications
+                        # count): can exceed 1 because Winograd executes 25/81 (F(3x3)) or 36/144 (F(4x4)) of the 3x3 multiplications
                         "frac_effective": round(effective / FP32_MFMA_PEAK_TFLOPS, 4)}
             if sustained_ghz:
                 # a GEMM launch costs a constant number of cycles; the clock it is given varies with operand values and
@@ -563,7 +563,7 @@ def main():
                        **({"backend": "gloo, ranks SHARING devices (VSPW_BENCH_SHARED_GPU test mode): plumbing check, "
                                       "not a measurement"} if SHARED_GPU_TEST else {})},
             # direct-convolution FLOPs of the step (5785 GFLOP/clip) per second against the fp32 MFMA
-            # peak: an EFFECTIVE fraction - the Winograd path executes 4/9 of the multiplications of its 3x3 convs
+            # peak: an EFFECTIVE fraction - the Winograd path executes 25/81 or 36/144 of the multiplications of its 3x3 convs
             "e2e_mfma_frac": round(GFLOP_PER_CLIP * 1e9 * clips_per_s / world / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
             if args.crop == CROP else None,
             "last_loss": round(last_loss, 5),

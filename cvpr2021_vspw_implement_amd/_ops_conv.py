@@ -102,10 +102,12 @@ def _wino_f3(d):
             # executed multiplications per (cin, cout) pair = tiles x positions.  Measured (tools/diag/wino3_probe.py,
             # profiles/r06_wino34_probe.log, us for the three passes, F(3x3) -> F(4x4)): F(4x4) wins where the GEMMs dominate
             # its 36-plane transforms, i.e. from 512 channels on - the heads' 1024 / 4096 -> 512 on undilated 60x60 maps
-            # (19 % fewer multiplications) 2837 -> 2446 and 2388 -> 2019, the dilated 512 -> 512 of layer 4 (30 -> 32 / 15 -> 16
-            # padding: 8 % fewer) 1530 -> 1472; it loses on 256 channels with dilation (503 -> 537) and on 128 (194 -> 207)
+            # (19 % fewer multiplications) 2852 -> 2389 and 2384 -> 2026, the dilated 512 -> 512 of layer 4 (30 -> 32 / 15 -> 16
+            # padding: 8 % fewer) 1529 -> 1442; it loses on 256 channels with dilation (507 -> 518) and ties on 128 (195 -> 196)
             t3, t4 = int(_C.query("vspw_wino3_tiles", ctypes.byref(d))), int(_C.query("vspw_wino4_tiles", ctypes.byref(d)))
-            m = 4 if (36 * t4 <= 0.95 * 25 * t3 and min(d.c, d.k) >= 512) else 3
+            # (... and from 256 channels on where 4 divides the sub-grid exactly - 19 % fewer: layer3.0's 490 -> 458)
+            m = 4 if ((36 * t4 <= 0.95 * 25 * t3 and min(d.c, d.k) >= 512) or
+                      (36 * t4 <= 0.85 * 25 * t3 and min(d.c, d.k) >= 256)) else 3
         else:
             m = 3 if ok3 else (4 if ok4 else 0)
         _wino_tile_cache[key] = m

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restric
 constexpr int TB = 8;
 
 template <int WM, bool FRONT>
-__global__ __launch_bounds__(256) void wino3_output_kernel(const float* __restrict__ m, const float* __restrict__ bias,
+__global__ __launch_bounds__(256, WM == 3 ? 3 : 2) void wino3_output_kernel(const float* __restrict__ m, const float* __restrict__ bias,
                                                      float* __restrict__ y, const float* __restrict__ relu_src,
                                                      const float* __restrict__ bn_y, const float* __restrict__ bn_mean,
                                                      const float* __restrict__ bn_invstd, float* __restrict__ stat_part,
@@ -256,15 +256,17 @@ __global__ __launch_bounds__(256) void wino3_output_kernel(const float* __restri
         mu = *reinterpret_cast<const f32x4*>(bn_mean + k);
         is = *reinterpret_cast<const f32x4*>(bn_invstd + k);
     }
-    // (F(4x4): the scheduler issues all 36 plane loads first - 300 registers, one wave per SIMD, 147 KB in flight per CU:
-    // what an HBM-bound gather wants.  A 256-register bound spills 50 of them to scratch and is slower.)
+    // (registers: F(3x3) 161-170 = three waves per SIMD, F(4x4) 229-239 = two; with per-plane 64-bit addresses they were 216 /
+    // 300 = two / one)
     f32x4 s4 = zero, q4 = zero;
     for (int tt = lane_t; tt < TB; tt += tpi_iter) {
         const int t = t0 + tt;
         if (t >= g.T) break;
         int img, sy, sx, ty, tx;
         tile_of(g, t, img, sy, sx, ty, tx);
-        const float* in = m + (size_t)t * K + k;
+        // plane bases are workgroup-uniform (scalar registers), the per-thread part of every plane address is ONE 32-bit
+        // element offset (36 / 25 64-bit addresses would cost 72 / 50 registers)
+        const unsigned in = (unsigned)t * (unsigned)K + (unsigned)k;
         f32x4 yy[WM][WM];
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256) void wino3_output_kernel(const float* __restri
         for (int a = 0; a < WN; ++a) {
             f32x4 mm[WN];
 #pragma unroll
-            for (int b = 0; b < WN; ++b) mm[b] = *reinterpret_cast<const f32x4*>(in + (size_t)(a * WN + b) * plane);
+            for (int b = 0; b < WN; ++b) mm[b] = *reinterpret_cast<const f32x4*>(m + (size_t)(a * WN + b) * plane + in);
             f32x4 p[WM];
 #pragma unroll
             for (int j = 0; j < WM; ++j) {
@@ -442,6 +444,8 @@ static size_t t_supported(const vspw_conv_desc* d) {
     Geom g;
     if (!geom<WM>(d, g)) return 0;
     if (d->c % 32 != 0 || d->k % 32 != 0) return 0;  // vector gathers + the v2 GEMM kernel on both sides
+    const long long cmax = d->c > d->k ? d->c : d->k;
+    if ((long long)g.T * cmax >= (1LL << 31)) return 0;  // 32-bit element offsets inside a plane (transform kernels)
     return (cl4_of(d->k) && cl4_of(d->c)) ? 1 : 0;
 }
 template <int WM>

@@ -973,3 +973,28 @@ def test_strided_scatter_is_the_adjoint_of_strided_sampling(dev, n, oh, ow, h, w
     dst = torch.full((n, h, w, c), -3.0, device=dev)
     _C.call("vspw_strided_scatter_nhwc", _p(src.to(dev)), _p(dst), n, oh, ow, h, w, c, stride, _stream())
     assert torch.equal(dst.cpu(), want)
+
+
+def test_winograd_tile_choice_on_the_bench_geometry(dev):
+    """ops._wino_f3: which Winograd tile a stride-1 3x3 of the bench workload (10 frames, 60x60) takes - the measured rule
+    of profiles/r06_wino34_probe.log: F(4x4) from 512 channels on (or 256 with an exact 4-tiling), F(3x3) below, F(2x2)
+    under 128 channels; the forced settings; one size for all three passes by construction (same descriptor)."""
+    from cvpr2021_vspw_implement_amd import ops
+    from cvpr2021_vspw_implement_amd._C import ConvDesc
+
+    def m(c, k, dil, n=10, h=60, w=60):
+        d = ConvDesc(n, h, w, c, h, w, k, 3, 3, 1, dil, dil, dil)
+        return ops._wino_f3(d) if ops._wino_ok(d) else -1
+
+    prev = ops.set_winograd_f3(True)
+    try:
+        assert m(256, 256, 2) == 3 and m(256, 256, 1) == 4 and m(128, 128, 1) == 3
+        assert m(512, 512, 4) == 4 and m(512, 512, 2) == 4 and m(1024, 512, 1) == 4 and m(4096, 512, 1, n=2) == 4
+        assert m(64, 64, 1) == -1                       # below VSPW_WINO_MINC: direct kernel
+        assert m(2048, 512, 1, n=1, h=60, w=107) == 4   # the 480x853 inference frame
+        ops.set_winograd_tile(3)
+        assert m(512, 512, 4) == 3 and m(1024, 512, 1) == 3
+        ops.set_winograd_tile(2)
+        assert m(512, 512, 4) == 0 and m(256, 256, 2) == 0
+    finally:
+        ops.set_winograd_f3(prev)

@@ -89,7 +89,7 @@ def _nn(*ptrs):
 
 def _wino_bytes(a, chan_idx, streams_full, m_idx=None, planes=16.0):
     d = a[0]._obj
-    T = int(_C.query({25.0: "vspw_wino3_tiles", 36.0: "vspw_wino4_tiles"}.get(planes, "vspw_wino_tiles"), ctypes.byref(d)))
+    T = int(_C.query({25.0: "vspw_wino3_tiles", 36.0: "vspw_wino4_tiles", 49.0: "vspw_wino5_tiles"}.get(planes, "vspw_wino_tiles"), ctypes.byref(d)))
     c = int(a[chan_idx])
     return 4.0 * c * (planes * T + d.n * d.h * d.w * streams_full)
 
@@ -117,6 +117,10 @@ _HBM_BYTES = {
     "vspw_wino4_input": lambda a: _wino_bytes(a, 2, 1, planes=36.0),
     "vspw_wino4_dy": lambda a: _wino_bytes(a, 2, 1, planes=36.0),
     "vspw_wino4_output": lambda a: _wino_bytes(a, 2, 1 + _nn(a[5], a[6], a[10]), planes=36.0),
+    # F(5x5,3x3): 49 planes
+    "vspw_wino5_input": lambda a: _wino_bytes(a, 2, 1, planes=49.0),
+    "vspw_wino5_dy": lambda a: _wino_bytes(a, 2, 1, planes=49.0),
+    "vspw_wino5_output": lambda a: _wino_bytes(a, 2, 1 + _nn(a[5], a[6], a[10]), planes=49.0),
 }
 
 

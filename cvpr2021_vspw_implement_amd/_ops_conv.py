@@ -39,7 +39,11 @@ _wino = {"enabled": os.environ.get("VSPW_WINOGRAD", "1") == "1", "min_c": int(os
          # (VSPW_WINO_TILE; VSPW_WINO_F3=0 is the old spelling of 2).  VSPW_WINO_F3_MINC: smallest channel count (both
          # sides) that leaves F(2x2)
          "tile": 2 if os.environ.get("VSPW_WINO_F3", "1") != "1" else int(os.environ.get("VSPW_WINO_TILE", "0")),
-         "f3_min_c": int(os.environ.get("VSPW_WINO_F3_MINC", "128")), "f3_launches": 0, "f4_launches": 0}
+         "f3_min_c": int(os.environ.get("VSPW_WINO_F3_MINC", "128")), "f3_launches": 0, "f4_launches": 0, "f5_launches": 0,
+         # F(5x5,3x3) (49/225 of the direct multiplications, conv-level rounding error 2.8x F(3x3)'s): taken in automatic mode
+         # where min(Cin, Cout) >= f5_min_c and max(Cin, Cout) >= f5_min_cmax (see _wino_f3)
+         "f5_dgrad": os.environ.get("VSPW_WINO_F5_DGRAD", "1") == "1",
+         "f5_min_c": int(os.environ.get("VSPW_WINO_F5_MINC", "512")), "f5_min_cmax": int(os.environ.get("VSPW_WINO_F5_MINCMAX", "0"))}
 _wino_tile_cache = {}
 
 
@@ -76,28 +80,42 @@ def set_winograd_f3(enabled):
 
 def set_winograd_tile(m):
     """0: automatic, 2 / 3 / 4: force F(m x m, 3x3) where the geometry allows it.  Returns the previous value."""
-    if m not in (0, 2, 3, 4):
+    if m not in (0, 2, 3, 4, 5):
         raise ValueError("Winograd tile %r" % (m,))
     prev = _wino["tile"]
     _wino["tile"] = m
     return False if prev == 2 else (True if prev == 0 else prev)
 
 
-def _wino_f3(d):
-    """Output tile edge m (3 or 4) when this (Winograd-eligible, see _wino_ok) convolution leaves F(2x2) in all three
-    passes - forward, data gradient and weight gradient decide alike, they share V - else 0."""
+def _wino_f3(d, data_gradient=False):
+    """Output tile edge m (3, 4 or 5) when this (Winograd-eligible, see _wino_ok) convolution leaves F(2x2), else 0.
+    Forward and weight gradient decide alike (they share V).  The DATA gradient shares nothing with them and its result
+    never reaches a forward activation, so in automatic mode it takes F(5x5) wherever that is supported (layers 2 / 3:
+    184 -> 153 us per 256-channel launch) - `VSPW_WINO_F5_DGRAD=0`: same tile as the other two passes."""
     t = _wino["tile"]
     if t == 2 or min(d.c, d.k) < _wino["f3_min_c"]:
         return 0
-    key = (t, d.n, d.h, d.w, d.c, d.k, d.dil, d.pad, d.pad_w, d.stride, d.kh, d.kw)
+    if data_gradient and t == 0 and _wino["f5_dgrad"]:
+        key = ("dgrad", d.n, d.h, d.w, d.c, d.k, d.dil, d.pad, d.pad_w, d.stride, d.kh, d.kw)
+        m = _wino_tile_cache.get(key)
+        if m is None:
+            m = _wino_tile_cache[key] = 5 if _C.query("vspw_wino5_supported", ctypes.byref(d)) == 1 else 0
+        if m:
+            return m
+    key = (t, _wino["f5_min_c"], _wino["f5_min_cmax"], d.n, d.h, d.w, d.c, d.k, d.dil, d.pad, d.pad_w, d.stride, d.kh, d.kw)
     m = _wino_tile_cache.get(key)
     if m is None:
         ok3 = _C.query("vspw_wino3_supported", ctypes.byref(d)) == 1
         ok4 = _C.query("vspw_wino4_supported", ctypes.byref(d)) == 1
         if t == 3:
             m = 3 if ok3 else 0
+        elif t == 5:
+            m = 5 if _C.query("vspw_wino5_supported", ctypes.byref(d)) == 1 else (3 if ok3 else 0)
         elif t == 4:
             m = 4 if ok4 else (3 if ok3 else 0)
+        elif (min(d.c, d.k) >= _wino["f5_min_c"] and max(d.c, d.k) >= _wino["f5_min_cmax"]
+              and _C.query("vspw_wino5_supported", ctypes.byref(d)) == 1):
+            m = 5
         elif ok3 and ok4:
             # executed multiplications per (cin, cout) pair = tiles x positions.  Measured (tools/diag/wino3_probe.py,
             # profiles/r06_wino34_probe.log, us for the three passes, F(3x3) -> F(4x4)): F(4x4) wins where the GEMMs dominate
@@ -119,7 +137,7 @@ def _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None,
     """_wino_conv through F(m x m, 3x3), m = 3 or 4: input transform, (m+2)^2 batched GEMMs, output transform
     (winograd_f3.hip)."""
     dev, st = src.device, _stream()
-    m = m or _wino_f3(d)
+    m = m or _wino_f3(d, data_gradient)
     P, api = (m + 2) * (m + 2), "vspw_wino%d_" % m
     T = int(_C.query(api + "tiles", ctypes.byref(d)))
     if u is None:
@@ -144,7 +162,7 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
     """dst = conv(src) through U, V, M (see winograd.hip); rows = output channels, reduce_c = channels of src.
     u: transformed weights supplied by the caller (inference: of the BatchNorm-folded weights).
     pending = (y_prev, scale_shift): src has not been written - the input transform evaluates it (see _fwd_apply)."""
-    if pending is None and u is None and _wino_f3(d):
+    if pending is None and u is None and _wino_f3(d, data_gradient):
         return _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front, part, what, None, addend, act)
     dev = src.device
     st = _stream()
@@ -387,7 +405,7 @@ def _wum_cache(m):
                            lambda k, c, kh, kw: _C.query("vspw_wino_weight_tiles", k, c))
 
 
-_wu3_copies = {3: _wum_cache(3), 4: _wum_cache(4)}
+_wu3_copies = {3: _wum_cache(3), 4: _wum_cache(4), 5: _wum_cache(5)}
 
 
 def _wino3_weights(w, data_gradient, m=3):
@@ -420,7 +438,7 @@ def conv2d_backward_data(dy, w, d, addend=None, bn_front=None, aff=None):
         if bn_front is not None:
             z, link = bn_front
             front = (z, link.y, link.mean, link.invstd)
-            fm = _wino_f3(d)
+            fm = _wino_f3(d, True)
             part = torch.empty((_C.query(("vspw_wino%d_stat_partials" % fm) if fm else "vspw_wino_stat_partials",
                                          ctypes.byref(d)), 2, d.c), device=dy.device, dtype=torch.float32)
         _wino_conv(d, dy, w, d.c, d.k, True, None, dx, front=front, part=part, what="dgrad")

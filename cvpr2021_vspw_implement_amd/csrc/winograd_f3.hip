@@ -31,16 +31,25 @@
 #include "common.h"
 
 // B^T [N][N], A^T [M][N] (fp32: exact binary fractions), G [N][3] (fp64); N = M + 2.  Generated from the Cook-Toom
-// construction of oracle/np_wino.py (points {0,1,-1,2,inf} and {0,1,-1,1/2,-2,inf}).
+// construction of oracle/np_wino.py (points {0,1,-1,2,inf}, {0,1,-1,1/2,-2,inf} and {0,1,-1,1/2,-1/2,2,inf}).
 __device__ constexpr float kBT3[5][5] = {{2.f, -1.f, -2.f, 1.f, 0.f}, {0.f, -2.f, -1.f, 1.f, 0.f}, {0.f, 2.f, -3.f, 1.f, 0.f}, {0.f, -1.f, 0.f, 1.f, 0.f}, {0.f, 2.f, -1.f, -2.f, 1.f}};
 __device__ constexpr float kAT3[3][5] = {{1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 2.f, 0.f}, {0.f, 1.f, 1.f, 4.f, 1.f}};
 __device__ constexpr double kG3[5][3] = {{1. / 2., 0., 0.}, {-1. / 2., -1. / 2., -1. / 2.}, {-1. / 6., 1. / 6., -1. / 6.}, {1. / 6., 1. / 3., 2. / 3.}, {0., 0., 1.}};
 __device__ constexpr float kBT4[6][6] = {{1.f, -3.f / 2.f, -2.f, 3.f / 2.f, 1.f, 0.f}, {0.f, -1.f, 1.f / 2.f, 5.f / 2.f, 1.f, 0.f}, {0.f, 1.f, -5.f / 2.f, 1.f / 2.f, 1.f, 0.f}, {0.f, -2.f, -1.f, 2.f, 1.f, 0.f}, {0.f, 1.f / 2.f, -1.f, -1.f / 2.f, 1.f, 0.f}, {0.f, 1.f, -3.f / 2.f, -2.f, 3.f / 2.f, 1.f}};
 __device__ constexpr float kAT4[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 1.f / 2.f, -2.f, 0.f}, {0.f, 1.f, 1.f, 1.f / 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 1.f / 8.f, -8.f, 1.f}};
 __device__ constexpr double kG4[6][3] = {{1., 0., 0.}, {1. / 3., 1. / 3., 1. / 3.}, {-1. / 3., 1. / 3., -1. / 3.}, {-16. / 15., -8. / 15., -4. / 15.}, {1. / 15., -2. / 15., 4. / 15.}, {0., 0., 1.}};
-template <int M> __device__ __forceinline__ constexpr float cBT(int a, int i) { if constexpr (M == 3) return kBT3[a][i]; else return kBT4[a][i]; }
-template <int M> __device__ __forceinline__ constexpr float cAT(int a, int i) { if constexpr (M == 3) return kAT3[a][i]; else return kAT4[a][i]; }
-template <int M> __device__ __forceinline__ constexpr double cG(int a, int i) { if constexpr (M == 3) return kG3[a][i]; else return kG4[a][i]; }
+__device__ constexpr float kBT5[7][7] = {{-1.f / 2.f, 1.f / 4.f, 5.f / 2.f, -5.f / 4.f, -2.f, 1.f, 0.f}, {0.f, 1.f / 2.f, 1.f / 4.f, -9.f / 4.f, -1.f, 1.f, 0.f}, {0.f, -1.f / 2.f, 3.f / 4.f, 7.f / 4.f, -3.f, 1.f, 0.f}, {0.f, 1.f, 3.f / 2.f, -2.f, -3.f / 2.f, 1.f, 0.f}, {0.f, -1.f, 5.f / 2.f, 0.f, -5.f / 2.f, 1.f, 0.f}, {0.f, 1.f / 4.f, 0.f, -5.f / 4.f, 0.f, 1.f, 0.f}, {0.f, -1.f / 2.f, 1.f / 4.f, 5.f / 2.f, -5.f / 4.f, -2.f, 1.f}};
+__device__ constexpr float kAT5[5][7] = {{1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 0.f}, {0.f, 1.f, -1.f, 1.f / 2.f, -1.f / 2.f, 2.f, 0.f}, {0.f, 1.f, 1.f, 1.f / 4.f, 1.f / 4.f, 4.f, 0.f}, {0.f, 1.f, -1.f, 1.f / 8.f, -1.f / 8.f, 8.f, 0.f}, {0.f, 1.f, 1.f, 1.f / 16.f, 1.f / 16.f, 16.f, 1.f}};
+__device__ constexpr double kG5[7][3] = {{-2., 0., 0.}, {-2. / 3., -2. / 3., -2. / 3.}, {-2. / 9., 2. / 9., -2. / 9.}, {16. / 9., 8. / 9., 4. / 9.}, {16. / 15., -8. / 15., 4. / 15.}, {2. / 45., 4. / 45., 8. / 45.}, {0., 0., 1.}};
+template <int M> __device__ __forceinline__ constexpr float cBT(int a, int i) { if constexpr (M == 3) return kBT3[a][i]; else if constexpr (M == 4) return kBT4[a][i]; else return kBT5[a][i]; }
+template <int M> __device__ __forceinline__ constexpr float cAT(int a, int i) { if constexpr (M == 3) return kAT3[a][i]; else if constexpr (M == 4) return kAT4[a][i]; else return kAT5[a][i]; }
+template <int M> __device__ __forceinline__ constexpr double cG(int a, int i) { if constexpr (M == 3) return kG3[a][i]; else if constexpr (M == 4) return kG4[a][i]; else return kG5[a][i]; }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int V> struct VecT { typedef f32x4 type; };
+template <> struct VecT<2> { typedef f32x2 type; };
+// channels per thread of the input / dY transforms: F(5x5)'s 49 accumulators x 4 would not fit the register file
+template <int WM> struct WinoVec { static constexpr int value = WM >= 5 ? 2 : 4; };
 
 struct Geom {
     int n, h, w, d;      // images, height, width, dilation
@@ -175,17 +184,19 @@ __global__ __launch_bounds__(256) void wino3_weight_multi_kernel(const vspw_wt_e
 template <int WM>
 __global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restrict__ x, float* __restrict__ v, Geom g, int C) {
     constexpr int WN = WM + 2;
-    const int c4n = C >> 2;
+    constexpr int VEC = WinoVec<WM>::value;
+    typedef typename VecT<VEC>::type vec;
+    const int c4n = C / VEC;
     // XCD-aware order: neighbouring tiles share two of their five patch columns / rows - keep them in one L2 (measured
     // before: FETCH_SIZE 83 MB per launch for a 37 MB input, workgroups of neighbouring tiles landing on eight XCDs)
     const long long gid = (long long)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
     if (gid >= (long long)g.T * c4n) return;
     const int t = (int)(gid / c4n);
-    const int c = (int)(gid - (long long)t * c4n) * 4;
+    const int c = (int)(gid - (long long)t * c4n) * VEC;
     int img, sy, sx, ty, tx;
     tile_of(g, t, img, sy, sx, ty, tx);
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[WN][WN];
+    const vec zero = (vec)(0.f);
+    vec acc[WN][WN];
 #pragma unroll
     for (int a = 0; a < WN; ++a)
 #pragma unroll
@@ -195,18 +206,18 @@ __global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restric
         const int gy = WM * ty - 1 + i;
         const int py = gy * g.d + sy;
         const bool oky = (gy >= 0) & (py < g.h);
-        f32x4 dd[WN];
+        vec dd[WN];
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int gx = WM * tx - 1 + j;
             const int px = gx * g.d + sx;
             const bool ok = oky & (gx >= 0) & (px < g.w);
-            dd[j] = ok ? *reinterpret_cast<const f32x4*>(x + (((size_t)img * g.h + py) * g.w + px) * C + c) : zero;
+            dd[j] = ok ? *reinterpret_cast<const vec*>(x + (((size_t)img * g.h + py) * g.w + px) * C + c) : zero;
         }
-        f32x4 r[WN];
+        vec r[WN];
 #pragma unroll
         for (int b = 0; b < WN; ++b) {
-            f32x4 s = zero;
+            vec s = zero;
 #pragma unroll
             for (int j = 0; j < WN; ++j)
                 if (cBT<WM>(b, j) != 0.f) s += cBT<WM>(b, j) * dd[j];
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restric
 #pragma unroll
     for (int a = 0; a < WN; ++a)
 #pragma unroll
-        for (int b = 0; b < WN; ++b) *reinterpret_cast<f32x4*>(out + (size_t)(a * WN + b) * plane) = acc[a][b];
+        for (int b = 0; b < WN; ++b) *reinterpret_cast<vec*>(out + (size_t)(a * WN + b) * plane) = acc[a][b];
 }
 
 // ------------------------------------------------------------------------------------------------ output
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restric
 constexpr int TB = 8;
 
 template <int WM, bool FRONT>
-__global__ __launch_bounds__(256, WM == 3 ? 3 : 2) void wino3_output_kernel(const float* __restrict__ m, const float* __restrict__ bias,
+__global__ __launch_bounds__(256, WM == 3 ? 3 : (WM == 4 ? 2 : 1)) void wino3_output_kernel(const float* __restrict__ m, const float* __restrict__ bias,
                                                      float* __restrict__ y, const float* __restrict__ relu_src,
                                                      const float* __restrict__ bn_y, const float* __restrict__ bn_mean,
                                                      const float* __restrict__ bn_invstd, float* __restrict__ stat_part,
@@ -345,15 +356,17 @@ __global__ __launch_bounds__(256, WM == 3 ? 3 : 2) void wino3_output_kernel(cons
 template <int WM>
 __global__ __launch_bounds__(256) void wino3_dy_kernel(const float* __restrict__ dy, float* __restrict__ dm, Geom g, int K) {
     constexpr int WN = WM + 2;
-    const int k4n = K >> 2;
+    constexpr int VEC = WinoVec<WM>::value;
+    typedef typename VecT<VEC>::type vec;
+    const int k4n = K / VEC;
     const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long long)g.T * k4n) return;
     const int t = (int)(gid / k4n);
-    const int k = (int)(gid - (long long)t * k4n) * 4;
+    const int k = (int)(gid - (long long)t * k4n) * VEC;
     int img, sy, sx, ty, tx;
     tile_of(g, t, img, sy, sx, ty, tx);
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc[WN][WN];
+    const vec zero = (vec)(0.f);
+    vec acc[WN][WN];
 #pragma unroll
     for (int a = 0; a < WN; ++a)
 #pragma unroll
@@ -361,17 +374,17 @@ __global__ __launch_bounds__(256) void wino3_dy_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
         const int oy = (WM * ty + i) * g.d + sy;
-        f32x4 d[WM];
+        vec d[WM];
 #pragma unroll
         for (int j = 0; j < WM; ++j) {
             const int ox = (WM * tx + j) * g.d + sx;
-            d[j] = (oy < g.h && ox < g.w) ? *reinterpret_cast<const f32x4*>(dy + (((size_t)img * g.h + oy) * g.w + ox) * K + k)
+            d[j] = (oy < g.h && ox < g.w) ? *reinterpret_cast<const vec*>(dy + (((size_t)img * g.h + oy) * g.w + ox) * K + k)
                                           : zero;
         }
-        f32x4 r[WN];
+        vec r[WN];
 #pragma unroll
         for (int b = 0; b < WN; ++b) {
-            f32x4 s = zero;
+            vec s = zero;
 #pragma unroll
             for (int j = 0; j < WM; ++j)
                 if (cAT<WM>(j, b) != 0.f) s += cAT<WM>(j, b) * d[j];
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(256) void wino3_dy_kernel(const float* __restrict__
 #pragma unroll
     for (int a = 0; a < WN; ++a)
 #pragma unroll
-        for (int b = 0; b < WN; ++b) *reinterpret_cast<f32x4*>(out + (size_t)(a * WN + b) * plane) = acc[a][b];
+        for (int b = 0; b < WN; ++b) *reinterpret_cast<vec*>(out + (size_t)(a * WN + b) * plane) = acc[a][b];
 }
 
 // dW[k][ky][kx][c] = (G^T dU G)[ky][kx]; dU [25][K][C]; one thread per (k, c), fp64 arithmetic
@@ -438,7 +451,7 @@ static int cl4_of(int K) {
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
-// vspw_wino3_* = F(3x3,3x3), vspw_wino4_* = F(4x4,3x3): the same nine calls (25 / 36 planes).
+// vspw_wino3_* = F(3x3,3x3), vspw_wino4_* = F(4x4,3x3), vspw_wino5_* = F(5x5,3x3): the same nine calls (25 / 36 / 49 planes).
 template <int WM>
 static size_t t_supported(const vspw_conv_desc* d) {
     Geom g;
@@ -471,7 +484,7 @@ template <int WM>
 static int t_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream) {
     Geom g;
     if (!geom<WM>(d, g) || !x || !v || channels <= 0 || channels % 4) return VSPW_EINVAL;
-    const long long items = (long long)g.T * (channels / 4);
+    const long long items = (long long)g.T * (channels / WinoVec<WM>::value);
     hipLaunchKernelGGL(wino3_input_kernel<WM>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), x,
                        v, g, channels);
     return vspw_launch_status();
@@ -500,7 +513,7 @@ template <int WM>
 static int t_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream) {
     Geom g;
     if (!geom<WM>(d, g) || !dy || !dm || channels <= 0 || channels % 4) return VSPW_EINVAL;
-    const long long items = (long long)g.T * (channels / 4);
+    const long long items = (long long)g.T * (channels / WinoVec<WM>::value);
     hipLaunchKernelGGL(wino3_dy_kernel<WM>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), dy, dm,
                        g, channels);
     return vspw_launch_status();
@@ -544,3 +557,4 @@ static int t_dw(const float* du, float* dw, int k, int c, void* stream) {
     }
 VSPW_WINO_M(wino3, 3)
 VSPW_WINO_M(wino4, 4)
+VSPW_WINO_M(wino5, 5)

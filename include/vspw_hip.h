@@ -273,6 +273,22 @@ int vspw_wino4_output(const vspw_conv_desc* d, const float* m, int channels, con
 int vspw_wino4_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream);
 int vspw_wino4_dw(const float* du, float* dw, int k, int c, void* stream);
 
+/* F(5x5,3x3): the same nine calls over 5x5 output tiles / 7x7 patches (points 0, 1, -1, 1/2, -1/2, 2, inf), 49 planes: 49/225 of
+ * the direct multiplications (1.96 per output pixel); 5 divides the 60 / 30 / 15 pixel sub-grid edges exactly.  Conv-level
+ * rounding error 2.8x F(3x3)'s (4.0e-6 on a layer-3 convolution); see winograd_f3.hip and DESIGN.md section 3 for where it is
+ * used. */
+size_t vspw_wino5_supported(const vspw_conv_desc* d);
+long long vspw_wino5_tiles(const vspw_conv_desc* d);
+size_t vspw_wino5_stat_partials(const vspw_conv_desc* d);
+int vspw_wino5_weights(const float* w, float* u, int k, int c, int data_gradient, void* stream);
+int vspw_wino5_weights_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream);
+int vspw_wino5_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream);
+int vspw_wino5_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
+                      const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
+                      float* stat_part, const float* addend, int act, void* stream);
+int vspw_wino5_dy(const vspw_conv_desc* d, const float* dy, int channels, float* dm, void* stream);
+int vspw_wino5_dw(const float* du, float* dw, int k, int c, void* stream);
+
 /* ---------------------------------------------------------------- batch norm (bn.hip) ------------- */
 /* Replaces SynchronizedBatchNorm2d.forward = F.batch_norm (models/sync_batchnorm/batchnorm.py:68-98) and its
  * autograd backward, fused with the ReLU / residual add / Dropout2d that follow it in models/resnet.py:40-51,75-90,

@@ -104,23 +104,26 @@ WINO_CASES = [c for c in CONV_CASES if c[5] == 3 and c[6] == 1 and min(c[1], c[4
     (2, 128, 7, 11, 160, 3, 1, 1, 1, False),
     (1, 160, 20, 9, 128, 3, 1, 2, 2, False),
     (2, 128, 16, 24, 128, 3, 1, 1, 1, True),   # exact 4x4 tiling
+    (2, 128, 15, 20, 128, 3, 1, 1, 1, False),  # exact 5x5 tiling
+    (1, 128, 30, 25, 160, 3, 1, 2, 2, False),  # 5x5 tiles on dilation-2 sub-grids, one ragged
 ]
 
 
-@pytest.mark.parametrize("wino_f3", [False, 3, 4, True], indirect=True)
+@pytest.mark.parametrize("wino_f3", [False, 3, 4, 5, True], indirect=True)
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_conv2d_winograd_tile_sizes(dev, case, wino_f3):
     """The parity gate of test_conv2d_fwd_bwd (against F.conv2d on the CPU) for every Winograd tile size, all three
     passes (ragged tiles, dilation sub-grids); checks that the F(3x3) / F(4x4) launches happened when asked for."""
     from cvpr2021_vspw_implement_amd import ops
 
-    before = (ops._wino["f3_launches"], ops._wino["f4_launches"])
+    keys = ("f3_launches", "f4_launches", "f5_launches")
+    before = [ops._wino[q] for q in keys]
     test_conv2d_fwd_bwd(dev, case)
-    got = (ops._wino["f3_launches"] - before[0], ops._wino["f4_launches"] - before[1])
-    if wino_f3 is True:
-        assert sum(got) == 3 and 0 in got  # one tile size for all three passes
+    got = tuple(ops._wino[q] - b for q, b in zip(keys, before))
+    if wino_f3 is True:  # forward and weight gradient share V: one tile size; the data gradient takes F(5x5)
+        assert sum(got) == 3 and got[2] >= 1 and sorted(got) in ([0, 0, 3], [0, 1, 2])
     else:
-        assert got == {False: (0, 0), 3: (3, 0), 4: (0, 3)}[wino_f3]
+        assert got == {False: (0, 0, 0), 3: (3, 0, 0), 4: (0, 3, 0), 5: (0, 0, 3)}[wino_f3]
 
 
 @pytest.mark.parametrize("wino_rows_tile", [12, 31, 22], indirect=True)
@@ -137,7 +140,7 @@ def test_conv2d_winograd_row_fused_form(dev, case, wino_rows_tile):
     test_conv2d_fwd_bwd(dev, case)
 
 
-@pytest.mark.parametrize("wino_rows_tile", [0, 12, 31, -3, -4], indirect=True)
+@pytest.mark.parametrize("wino_rows_tile", [0, 12, 31, -3, -4, -5], indirect=True)
 @pytest.mark.parametrize("dil,h,w", [(1, 12, 13), (2, 14, 14), (4, 15, 15)])
 def test_winograd_path_equals_direct_path_in_a_fused_chain(dev, dil, h, w, wino_rows_tile):
     """1x1 conv+BN+ReLU -> 3x3 conv+BN+ReLU (fuse_input: the 3x3 data gradient carries the first node's BatchNorm-backward
@@ -977,24 +980,26 @@ def test_strided_scatter_is_the_adjoint_of_strided_sampling(dev, n, oh, ow, h, w
 
 def test_winograd_tile_choice_on_the_bench_geometry(dev):
     """ops._wino_f3: which Winograd tile a stride-1 3x3 of the bench workload (10 frames, 60x60) takes - the measured rule
-    of profiles/r06_wino34_probe.log: F(4x4) from 512 channels on (or 256 with an exact 4-tiling), F(3x3) below, F(2x2)
-    under 128 channels; the forced settings; one size for all three passes by construction (same descriptor)."""
+    of profiles/r06_wino345_probe.log and r06_f5_eval.log: forward + weight gradient (they share V) F(5x5) from 512 channels
+    on (heads, layer 4: their error is not amplified by many later blocks), F(4x4) on 256 channels with an exact 4-tiling,
+    F(3x3) otherwise, nothing under 128 channels; the data gradient F(5x5) everywhere; the forced settings."""
     from cvpr2021_vspw_implement_amd import ops
     from cvpr2021_vspw_implement_amd._C import ConvDesc
 
-    def m(c, k, dil, n=10, h=60, w=60):
+    def m(c, k, dil, n=10, h=60, w=60, dgrad=False):
         d = ConvDesc(n, h, w, c, h, w, k, 3, 3, 1, dil, dil, dil)
-        return ops._wino_f3(d) if ops._wino_ok(d) else -1
+        return ops._wino_f3(d, dgrad) if ops._wino_ok(d) else -1
 
     prev = ops.set_winograd_f3(True)
     try:
         assert m(256, 256, 2) == 3 and m(256, 256, 1) == 4 and m(128, 128, 1) == 3
-        assert m(512, 512, 4) == 4 and m(512, 512, 2) == 4 and m(1024, 512, 1) == 4 and m(4096, 512, 1, n=2) == 4
+        assert m(512, 512, 4) == 5 and m(512, 512, 2) == 5 and m(1024, 512, 1) == 5 and m(4096, 512, 1, n=2) == 5
+        assert m(256, 256, 2, dgrad=True) == 5 and m(128, 128, 1, dgrad=True) == 5 and m(512, 512, 4, dgrad=True) == 5
         assert m(64, 64, 1) == -1                       # below VSPW_WINO_MINC: direct kernel
-        assert m(2048, 512, 1, n=1, h=60, w=107) == 4   # the 480x853 inference frame
+        assert m(2048, 512, 1, n=1, h=60, w=107) == 5   # the 480x853 inference frame
         ops.set_winograd_tile(3)
-        assert m(512, 512, 4) == 3 and m(1024, 512, 1) == 3
+        assert m(512, 512, 4) == 3 and m(1024, 512, 1) == 3 and m(256, 256, 2, dgrad=True) == 3
         ops.set_winograd_tile(2)
-        assert m(512, 512, 4) == 0 and m(256, 256, 2) == 0
+        assert m(512, 512, 4) == 0 and m(256, 256, 2) == 0 and m(256, 256, 2, dgrad=True) == 0
     finally:
         ops.set_winograd_f3(prev)

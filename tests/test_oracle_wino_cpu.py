@@ -13,10 +13,11 @@ from oracle import np_ops as O
 from oracle import np_wino as W
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-POINTS = {2: [0, 1, -1], 3: [0, 1, -1, 2], 4: [0, 1, -1, Fraction(1, 2), -2]}
+POINTS = {2: [0, 1, -1], 3: [0, 1, -1, 2], 4: [0, 1, -1, Fraction(1, 2), -2],
+          5: [0, 1, -1, Fraction(1, 2), Fraction(-1, 2), 2]}
 
 
-@pytest.mark.parametrize("m", [2, 3, 4])
+@pytest.mark.parametrize("m", [2, 3, 4, 5])
 @pytest.mark.parametrize("dil,h,w", [(1, 7, 9), (2, 11, 8), (4, 15, 13)])
 def test_winograd_emulation_is_exact_in_float64(m, dil, h, w):
     rng = np.random.default_rng(10 * m + dil)
@@ -41,7 +42,7 @@ def test_winograd_emulation_is_exact_in_float64(m, dil, h, w):
         O.set_dtype(np.float32)
 
 
-@pytest.mark.parametrize("m", [3, 4])
+@pytest.mark.parametrize("m", [3, 4, 5])
 def test_kernel_tables_are_the_cook_toom_construction(m):
     src = open(os.path.join(ROOT, "cvpr2021_vspw_implement_amd", "csrc", "winograd_f3.hip")).read()
 

@@ -49,7 +49,7 @@ def main():
     ops.set_wgrad_side_stream(False)
     print("%-24s %-8s %9s %9s %9s %9s   %s" % ("shape", "tile", "fwd us", "dgrad us", "wgrad us", "sum us", "rel diff of (y, dx, dw) vs F(2x2)"))
     saved = {}
-    total = {False: 0.0, 3: 0.0, 4: 0.0}
+    total = {False: 0.0, 3: 0.0, 4: 0.0, 5: 0.0}
     for name, n, h, w, c, k, dil, per_step in SHAPES:
         if flt and flt not in name:
             continue
@@ -58,7 +58,7 @@ def main():
         zs = [ops.empty_nhwc(n, c, h, w, dev).normal_() for _ in range(SETS)]   # ReLU source / BN y of the producer
         wt = (torch.randn(k, c, 3, 3, device=dev) * (2.0 / (9 * c)) ** 0.5).contiguous(memory_format=torch.channels_last)
         mean, invstd = torch.zeros(c, device=dev), torch.ones(c, device=dev)
-        for f3 in (False, 3, 4):
+        for f3 in (False, 3, 4, 5):
             ops.set_winograd_f3(f3)
             outs = {}
 
@@ -93,7 +93,7 @@ def main():
             outs.clear()
         del xs, dys, zs
         torch.cuda.empty_cache()
-    print("per step (launch counts of TCB-PSP R101): F(2x2) %.2f ms, F(3x3) %.2f ms, F(4x4) %.2f ms" % (total[False] / 1e3, total[3] / 1e3, total[4] / 1e3))
+    print("per step (launch counts of TCB-PSP R101): F(2x2) %.2f ms, F(3x3) %.2f ms, F(4x4) %.2f ms, F(5x5) %.2f ms" % (total[False] / 1e3, total[3] / 1e3, total[4] / 1e3, total[5] / 1e3))
 
 
 if __name__ == "__main__":

@@ -29,6 +29,7 @@ CANDIDATES = [
     ("F(3x3) {0,1/2,-1/2,2}", (3, [0, F(1, 2), F(-1, 2), 2])),
     ("F(4x4) {0,1,-1,2,-2}", (4, [0, 1, -1, 2, -2])),
     ("F(4x4) {0,1,-1,1/2,-2}", (4, [0, 1, -1, F(1, 2), -2])),
+    ("F(5x5) {0,1,-1,1/2,-1/2,2}", (5, [0, 1, -1, F(1, 2), F(-1, 2), 2])),
 ]
 if os.environ.get("CANDS"):
     sel = [int(i) for i in os.environ["CANDS"].split(",")]

@@ -87,6 +87,22 @@ def set_winograd_tile(m):
     return False if prev == 2 else (True if prev == 0 else prev)
 
 
+class winograd_tile_hint(object):
+    """`with winograd_tile_hint(5): ...` - the FORWARD convolutions issued inside take F(m x m, 3x3) where the geometry
+    allows it and the mode is automatic (their weight gradients follow through the kept V).  The model uses it for where
+    a layer sits in the network: rounding error injected late is amplified by few later blocks (models/resnet.py)."""
+
+    def __init__(self, m):
+        self.m = m
+
+    def __enter__(self):
+        self.prev, _wino["hint"] = _wino.get("hint", 0), (self.m or 0)
+
+    def __exit__(self, *a):
+        _wino["hint"] = self.prev
+        return False
+
+
 def _wino_f3(d, data_gradient=False):
     """Output tile edge m (3, 4 or 5) when this (Winograd-eligible, see _wino_ok) convolution leaves F(2x2), else 0.
     Forward and weight gradient decide alike (they share V).  The DATA gradient shares nothing with them and its result
@@ -95,6 +111,14 @@ def _wino_f3(d, data_gradient=False):
     t = _wino["tile"]
     if t == 2 or min(d.c, d.k) < _wino["f3_min_c"]:
         return 0
+    h = _wino.get("hint", 0)
+    if not data_gradient and t == 0 and h in (3, 4, 5):
+        key = ("hint", h, d.n, d.h, d.w, d.c, d.k, d.dil, d.pad, d.pad_w, d.stride, d.kh, d.kw)
+        m = _wino_tile_cache.get(key)
+        if m is None:
+            m = _wino_tile_cache[key] = h if _C.query("vspw_wino%d_supported" % h, ctypes.byref(d)) == 1 else 0
+        if m:
+            return m
     if data_gradient and t == 0 and _wino["f5_dgrad"]:
         key = ("dgrad", d.n, d.h, d.w, d.c, d.k, d.dil, d.pad, d.pad_w, d.stride, d.kh, d.kw)
         m = _wino_tile_cache.get(key)
@@ -522,6 +546,8 @@ def _wino_wgrad(dy, x, d, dw, v=None):
     v: the input transform kept by the forward pass (recomputed from x when absent)."""
     dev, st = dy.device, _stream()
     fm = _wino_f3(d)
+    if v is not None and v.dim() == 3 and int(v.shape[0]) in (25, 36, 49) and fm:
+        fm = {25: 3, 36: 4, 49: 5}[int(v.shape[0])]  # the tile the forward pass took (it may have carried a hint)
     if fm:
         P, api = (fm + 2) * (fm + 2), "vspw_wino%d_" % fm
         T = int(_C.query(api + "tiles", ctypes.byref(d)))

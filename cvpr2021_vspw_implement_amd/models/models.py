@@ -184,6 +184,18 @@ class ResnetDilated(_ResnetTrunk):
             orig_resnet.layer4.apply(partial(self._nostride_dilate, dilate=4))
         elif dilate_scale == 16:
             orig_resnet.layer4.apply(partial(self._nostride_dilate, dilate=2))
+        # Winograd tile by depth (ops.winograd_tile_hint): the 3x3 of the LAST three quarters of layer 3's blocks takes
+        # F(5x5,3x3) - 1.96 multiplications per output instead of 2.78, conv-level rounding error 2.8x - because what a late
+        # block injects is amplified by few later blocks; the first quarter keeps F(3x3).  Measured on the full-size vectors
+        # (profiles/r06_f5_eval.log): raw-weight excess over the reference's own fp32 0.87-1.13 with the tail at 0, 0.5 and
+        # 0.75 alike, 1.3-1.7 (four gates red) with F(5x5) in every block.  VSPW_WINO_F5_L3_TAIL = fraction (0 = none).
+        import os
+
+        tail = float(os.environ.get("VSPW_WINO_F5_L3_TAIL", "0.75"))
+        blocks = list(orig_resnet.layer3)
+        for i, blk in enumerate(blocks):
+            if i >= len(blocks) - int(round(tail * len(blocks))) and tail > 0:
+                blk._vspw_wino_tile = 5
         self._adopt(orig_resnet)
 
     def _nostride_dilate(self, m, dilate):

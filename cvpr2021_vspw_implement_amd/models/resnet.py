@@ -106,7 +106,9 @@ class Bottleneck(nn.Module):
         else:
             out = vnn.conv_bn_act(x, self.conv1, self.bn1, relu=True, defer_apply=_DEFER_CONV1)
         # conv1's output is only read by conv2, conv2's only by conv3 (pointwise: it may evaluate bn2 + ReLU itself)
-        out = vnn.conv_bn_act(out, self.conv2, self.bn2, relu=True, fuse_input=True, defer_apply=_DEFER_CONV2)
+        # (a block late in its stage may ask for a larger Winograd tile: see ResnetDilated / ops.winograd_tile_hint)
+        with ops.winograd_tile_hint(getattr(self, "_vspw_wino_tile", 0)):
+            out = vnn.conv_bn_act(out, self.conv2, self.bn2, relu=True, fuse_input=True, defer_apply=_DEFER_CONV2)
         return vnn.conv_bn_act(out, self.conv3, self.bn3, relu=True, residual=_residual_branch(self, skip),
                                fuse_input=True, defer_apply=defer_output)
 

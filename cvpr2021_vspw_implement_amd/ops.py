@@ -28,7 +28,7 @@ from ._ops_conv import (  # noqa: F401 (re-exported: callers use ops.<name>)
     _wino_ok, _wino_takes_pending, _wino_weights, _wino_wgrad, _wt_alloc, _wt_cache, _wt_copies, _wt_key,
     _wt_single, _wu_alloc, _wu_copies, _wu_single, colsum, conv2d, conv2d_backward_data, conv2d_backward_weight,
     conv2d_forward, drop_weight_transpose_cache, join_side_streams, set_accum_chunk, set_wgrad_side_stream, set_winograd,
-    _wino3_conv, _wino3_weights, _wino_f3, _wu3_copies, accum_chunk_supported, set_winograd_f3, set_winograd_tile)
+    _wino3_conv, _wino3_weights, _wino_f3, _wu3_copies, accum_chunk_supported, set_winograd_f3, set_winograd_tile, winograd_tile_hint)
 from ._ops_bn import (  # noqa: F401 (re-exported: callers use ops.<name>)
     BNLink, BatchNormActFn, ConvBNActFn, _BN_SMALL_ROWS, _all_reduce_sums, _bn_fusion, _conv_bn_folded,
     _decisions, _finalize_name, _infer_fold, _sync_finalize, _sync_group, _sync_world, batch_norm_act,

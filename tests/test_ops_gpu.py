@@ -1003,3 +1003,33 @@ def test_winograd_tile_choice_on_the_bench_geometry(dev):
         assert m(512, 512, 4) == 0 and m(256, 256, 2) == 0 and m(256, 256, 2, dgrad=True) == 0
     finally:
         ops.set_winograd_f3(prev)
+
+
+def test_winograd_tile_hint_is_followed_by_forward_and_weight_gradient(dev):
+    """ops.winograd_tile_hint (the model's "late block" request, models/models.py ResnetDilated): a 256-channel dilated 3x3
+    - F(3x3) by the automatic rule - takes F(5x5) in the forward pass issued under the hint, its weight gradient follows
+    through the kept V, the data gradient is F(5x5) anyway; results against F.conv2d on the CPU as in test_conv2d_fwd_bwd."""
+    from cvpr2021_vspw_implement_amd import ops
+
+    case = (2, 256, 20, 20, 256, 3, 1, 2, 2, False)
+    prev = ops.set_winograd_f3(True)
+    try:
+        keys = ("f3_launches", "f4_launches", "f5_launches")
+        before = [ops._wino[q] for q in keys]
+        test_conv2d_fwd_bwd(dev, case)
+        assert tuple(ops._wino[q] - b for q, b in zip(keys, before)) == (2, 0, 1)
+        before = [ops._wino[q] for q in keys]
+        orig = ops.conv2d
+
+        def hinted(*a, **k):
+            with ops.winograd_tile_hint(5):
+                return orig(*a, **k)
+
+        ops.conv2d = hinted
+        try:
+            test_conv2d_fwd_bwd(dev, case)
+        finally:
+            ops.conv2d = orig
+        assert tuple(ops._wino[q] - b for q, b in zip(keys, before)) == (0, 0, 3)
+    finally:
+        ops.set_winograd_f3(prev)

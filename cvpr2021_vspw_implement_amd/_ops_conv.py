@@ -157,7 +157,7 @@ def _wino_f3(d, data_gradient=False):
 
 
 def _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, part=None, what="fwd", u=None,
-                addend=None, act=0, m=None):
+                addend=None, act=0, m=None, pending=None):
     """_wino_conv through F(m x m, 3x3), m = 3 or 4: input transform, (m+2)^2 batched GEMMs, output transform
     (winograd_f3.hip)."""
     dev, st = src.device, _stream()
@@ -167,7 +167,10 @@ def _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None,
     if u is None:
         u = _wino3_weights(w, data_gradient, m)
     v = torch.empty((P, T, reduce_c), device=dev, dtype=torch.float32)
-    _C.call(api + "input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
+    if pending is not None:  # src = relu(scale*y + shift) is evaluated (and written) by the transform, see _fwd_apply
+        _C.call(api + "input_apply", ctypes.byref(d), _p(pending[0]), _p(pending[1]), _p(src), reduce_c, _p(v), st)
+    else:
+        _C.call(api + "input", ctypes.byref(d), _p(src), reduce_c, _p(v), st)
     mm = torch.empty((P, T, rows), device=dev, dtype=torch.float32)
     with _Timed("igemm_nt_kernel", 2.0 * P * T * rows * reduce_c, _conv_tag(d, what + "-wino%d" % m), _conv_flops(d)):
         _C.call("vspw_bmm_nt", _p(v), _p(u), _p(mm), P, T, rows, reduce_c, st)
@@ -186,8 +189,9 @@ def _wino_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front=None, 
     """dst = conv(src) through U, V, M (see winograd.hip); rows = output channels, reduce_c = channels of src.
     u: transformed weights supplied by the caller (inference: of the BatchNorm-folded weights).
     pending = (y_prev, scale_shift): src has not been written - the input transform evaluates it (see _fwd_apply)."""
-    if pending is None and u is None and _wino_f3(d, data_gradient):
-        return _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front, part, what, None, addend, act)
+    if u is None and _wino_f3(d, data_gradient):
+        return _wino3_conv(d, src, w, rows, reduce_c, data_gradient, bias, dst, front, part, what, None, addend, act,
+                           pending=pending)
     dev = src.device
     st = _stream()
     T = int(_C.query("vspw_wino_tiles", ctypes.byref(d)))
@@ -243,7 +247,7 @@ def _wino_takes_pending(d, pending, wgrad):
     of its own (V kept for the weight gradient; the fused-operand GEMM reads every pixel four times per position) and
     the deferred node has no residual branch."""
     return (_fwd_apply["wino"] and pending[2] is None and _wino["keep_v"] and bool(wgrad) and _wino["wgrad"]
-            and not _wino["fuse_fwd"] and d.c % 4 == 0 and not _wino_f3(d))
+            and not _wino["fuse_fwd"] and d.c % 4 == 0)
 
 
 def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None, wgrad=True):
@@ -263,7 +267,7 @@ def conv2d_forward(x, w, bias, stride, pad, dil, want_stats=False, pending=None,
     part = None
     if _wino_ok(d) and (pending is None or _wino_takes_pending(d, pending, wgrad)):
         if want_stats:
-            fm = _wino_f3(d) if pending is None else 0
+            fm = _wino_f3(d)
             nparts = _C.query(("vspw_wino%d_stat_partials" % fm) if fm else "vspw_wino_stat_partials", ctypes.byref(d))
             part = torch.empty((nparts, 2, k), device=x.device, dtype=torch.float32)
         # the input transform is kept for this convolution's weight gradient (same V: saves its recomputation there) -

@@ -181,8 +181,14 @@ __global__ __launch_bounds__(256) void wino3_weight_multi_kernel(const vspw_wt_e
 // ------------------------------------------------------------------------------------------------ input
 // V[xi][t][c] = (B^T d B)[xi].  One thread: one tile, 4 channels; patch rows are consumed as they arrive
 // (row i contributes BT[a][i] * (d[i][.] B)[b] to every V[a][b]).
-template <int WM>
-__global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restrict__ x, float* __restrict__ v, Geom g, int C) {
+// APPLY: x has not been written yet - it is relu(scale * y + shift) of the conv+BN+ReLU node that produces this convolution's
+// input (its BatchNorm apply deferred into its one reader, ops._fwd_apply; cf. wino_input_kernel<true> in winograd.hip): the
+// patch is evaluated from y (same expression tree as bn_apply_kernel: bit-identical values; padding stays zero) and the tile's
+// own M x M pixels - every pixel belongs to exactly one tile - are written to zout for the backward pass.
+template <int WM, bool APPLY>
+__global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restrict__ x, float* __restrict__ v, Geom g, int C,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ zout) {
     constexpr int WN = WM + 2;
     constexpr int VEC = WinoVec<WM>::value;
     typedef typename VecT<VEC>::type vec;
@@ -196,6 +202,11 @@ __global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restric
     int img, sy, sx, ty, tx;
     tile_of(g, t, img, sy, sx, ty, tx);
     const vec zero = (vec)(0.f);
+    vec sc = zero, sh = zero;
+    if (APPLY) {
+        sc = *reinterpret_cast<const vec*>(scale + c);
+        sh = *reinterpret_cast<const vec*>(shift + c);
+    }
     vec acc[WN][WN];
 #pragma unroll
     for (int a = 0; a < WN; ++a)
@@ -212,7 +223,16 @@ __global__ __launch_bounds__(256) void wino3_input_kernel(const float* __restric
             const int gx = WM * tx - 1 + j;
             const int px = gx * g.d + sx;
             const bool ok = oky & (gx >= 0) & (px < g.w);
-            dd[j] = ok ? *reinterpret_cast<const vec*>(x + (((size_t)img * g.h + py) * g.w + px) * C + c) : zero;
+            const size_t e = (((size_t)img * g.h + py) * g.w + px) * C + c;
+            vec val = ok ? *reinterpret_cast<const vec*>(x + e) : zero;
+            if (APPLY) {
+                val = val * sc + sh;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) val[q] = val[q] > 0.f ? val[q] : 0.f;
+                if (!ok) val = zero;
+                if (ok && i >= 1 && i <= WM && j >= 1 && j <= WM) *reinterpret_cast<vec*>(zout + e) = val;
+            }
+            dd[j] = val;
         }
         vec r[WN];
 #pragma unroll
@@ -481,12 +501,19 @@ static int t_weights_multi(const vspw_wt_entry* entries, int n_entries, long lon
     return vspw_launch_status();
 }
 template <int WM>
-static int t_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream) {
+static int t_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream,
+                   const float* scale_shift = nullptr, float* z_out = nullptr) {
     Geom g;
-    if (!geom<WM>(d, g) || !x || !v || channels <= 0 || channels % 4) return VSPW_EINVAL;
+    if (!geom<WM>(d, g) || !x || !v || channels <= 0 || channels % 4 || (scale_shift != nullptr) != (z_out != nullptr))
+        return VSPW_EINVAL;
     const long long items = (long long)g.T * (channels / WinoVec<WM>::value);
-    hipLaunchKernelGGL(wino3_input_kernel<WM>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, vspw_stream(stream), x,
-                       v, g, channels);
+    const dim3 grid((unsigned)((items + 255) / 256));
+    if (scale_shift)
+        hipLaunchKernelGGL((wino3_input_kernel<WM, true>), grid, dim3(256), 0, vspw_stream(stream), x, v, g, channels,
+                           scale_shift, scale_shift + channels, z_out);
+    else
+        hipLaunchKernelGGL((wino3_input_kernel<WM, false>), grid, dim3(256), 0, vspw_stream(stream), x, v, g, channels,
+                           nullptr, nullptr, nullptr);
     return vspw_launch_status();
 }
 template <int WM>
@@ -542,6 +569,10 @@ static int t_dw(const float* du, float* dw, int k, int c, void* stream) {
     }                                                                                                                       \
     extern "C" int vspw_##NAME##_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream) {     \
         return t_input<WM>(d, x, channels, v, stream);                                                                      \
+    }                                                                                                                       \
+    extern "C" int vspw_##NAME##_input_apply(const vspw_conv_desc* d, const float* y, const float* scale_shift,             \
+                                             float* z_out, int channels, float* v, void* stream) {                          \
+        return t_input<WM>(d, y, channels, v, stream, scale_shift, z_out);                                                  \
     }                                                                                                                       \
     extern "C" int vspw_##NAME##_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y, \
                                         const float* relu_src, const float* bn_y, const float* bn_mean,                     \

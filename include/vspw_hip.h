@@ -253,6 +253,9 @@ size_t vspw_wino3_stat_partials(const vspw_conv_desc* d);
 int vspw_wino3_weights(const float* w, float* u, int k, int c, int data_gradient, void* stream);
 int vspw_wino3_weights_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream);
 int vspw_wino3_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream);
+/* ... of z = relu(scale*y + shift), not materialised (see vspw_wino_input_apply): V from y, z written to z_out. */
+int vspw_wino3_input_apply(const vspw_conv_desc* d, const float* y, const float* scale_shift, float* z_out, int channels,
+                           float* v, void* stream);
 int vspw_wino3_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
                       const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
                       float* stat_part, const float* addend, int act, void* stream);
@@ -267,6 +270,9 @@ size_t vspw_wino4_stat_partials(const vspw_conv_desc* d);
 int vspw_wino4_weights(const float* w, float* u, int k, int c, int data_gradient, void* stream);
 int vspw_wino4_weights_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream);
 int vspw_wino4_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream);
+/* ... of z = relu(scale*y + shift), not materialised (see vspw_wino_input_apply): V from y, z written to z_out. */
+int vspw_wino4_input_apply(const vspw_conv_desc* d, const float* y, const float* scale_shift, float* z_out, int channels,
+                           float* v, void* stream);
 int vspw_wino4_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
                       const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
                       float* stat_part, const float* addend, int act, void* stream);
@@ -283,6 +289,9 @@ size_t vspw_wino5_stat_partials(const vspw_conv_desc* d);
 int vspw_wino5_weights(const float* w, float* u, int k, int c, int data_gradient, void* stream);
 int vspw_wino5_weights_multi(const vspw_wt_entry* entries, int n_entries, long long total_tiles, void* stream);
 int vspw_wino5_input(const vspw_conv_desc* d, const float* x, int channels, float* v, void* stream);
+/* ... of z = relu(scale*y + shift), not materialised (see vspw_wino_input_apply): V from y, z written to z_out. */
+int vspw_wino5_input_apply(const vspw_conv_desc* d, const float* y, const float* scale_shift, float* z_out, int channels,
+                           float* v, void* stream);
 int vspw_wino5_output(const vspw_conv_desc* d, const float* m, int channels, const float* bias, float* y,
                       const float* relu_src, const float* bn_y, const float* bn_mean, const float* bn_invstd,
                       float* stat_part, const float* addend, int act, void* stream);

@@ -322,7 +322,7 @@ def test_block_output_evaluated_by_the_next_conv1(dev, n, cm, c, h, w, k, fused,
         _close(got.grad, want.grad, 5e-4, what)
 
 
-@pytest.mark.parametrize("wino_f3", [False], indirect=True)  # the deferred apply exists for the F(2x2) input transform only
+@pytest.mark.parametrize("wino_f3", [False, 3, 4, 5], indirect=True)
 @pytest.mark.parametrize("dil,h,w,c1", [(2, 13, 14, 128), (1, 9, 11, 256), (4, 15, 15, 128)])
 def test_conv1_apply_evaluated_by_the_winograd_input_transform(dev, dil, h, w, c1, wino_f3):
     """relu(bn1(conv1(x))) left to conv2's Winograd input transform (models/resnet.py:76-79, vspw_wino_input_apply): the
